@@ -1,0 +1,148 @@
+"""ctypes loader for libaria_orb_hip.so (the C-ABI declared in include/aria_orb_hip.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libaria_orb_hip.so")
+
+# byte-for-byte aria::core::KeyPoint / aria::core::Match (reference include/core/Types.hpp:9-15, :97-101)
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+MATCH_DTYPE = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("distance", "<f4")])
+
+ARIA_OK = 0
+ARIA_E_OUTPUT_TOO_SMALL = -5
+ARIA_E_NOT_PENDING = -8
+
+# every symbol include/aria_orb_hip.h declares
+EXPORTS = [
+    "aria_status_string", "aria_abi_version", "aria_last_hip_error",
+    "aria_orb_default_config", "aria_orb_create", "aria_orb_destroy", "aria_orb_set_max_features",
+    "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_extract", "aria_orb_extract_async",
+    "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream",
+    "aria_orb_level_info", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
+    "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
+    "aria_matcher_knn2", "aria_matcher_match_batch_device", "aria_matcher_match_db_device",
+    "aria_matcher_stream", "aria_matcher_sync", "aria_synth_frame_pair", "aria_synth_sequence",
+]
+
+
+class OrbConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("stream", C.c_void_p), ("max_width", C.c_int),
+                ("max_height", C.c_int), ("max_features", C.c_int), ("max_batch", C.c_int),
+                ("blur_tie_mode", C.c_int), ("cand_cap_scale", C.c_int)]
+
+
+class MatcherConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("stream", C.c_void_p), ("max_query", C.c_int),
+                ("max_train", C.c_int)]
+
+
+class AriaError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        detail = ""
+        try:
+            detail = load_library().aria_last_hip_error().decode()
+        except Exception:
+            pass
+        super().__init__("%s failed: %s (%d)%s" % (where, status_string(status), status,
+                                                   (" [" + detail + "]") if detail else ""))
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(_SO):
+        os.remove(_SO)
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library. Never falls back to anything else: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _SO)
+    L = C.CDLL(_SO)
+    L.aria_status_string.restype = C.c_char_p
+    L.aria_last_hip_error.restype = C.c_char_p
+    L.aria_orb_stream.restype = C.c_void_p
+    L.aria_matcher_stream.restype = C.c_void_p
+    L.aria_orb_destroy.restype = None
+    L.aria_matcher_destroy.restype = None
+    L.aria_orb_destroy.argtypes = [C.c_void_p]
+    L.aria_matcher_destroy.argtypes = [C.c_void_p]
+    L.aria_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.POINTER(C.c_int)]
+    L.aria_orb_extract_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.aria_orb_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.aria_orb_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.aria_orb_check.argtypes = [C.c_void_p]
+    L.aria_orb_stream.argtypes = [C.c_void_p]
+    L.aria_orb_set_max_features.argtypes = [C.c_void_p, C.c_int]
+    L.aria_orb_get_max_features.argtypes = [C.c_void_p]
+    L.aria_orb_kp_capacity.argtypes = [C.c_void_p]
+    L.aria_orb_level_info.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.aria_orb_debug_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.aria_orb_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int64)]
+    L.aria_matcher_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                     C.c_int, C.POINTER(C.c_int)]
+    L.aria_matcher_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.aria_matcher_match_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    L.aria_matcher_match_db_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int64, C.c_double, C.c_void_p]
+    L.aria_matcher_stream.argtypes = [C.c_void_p]
+    L.aria_matcher_sync.argtypes = [C.c_void_p]
+    L.aria_synth_frame_pair.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.aria_synth_sequence.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+def status_string(status):
+    return load_library().aria_status_string(int(status)).decode()
+
+
+def abi_version():
+    return load_library().aria_abi_version()
+
+
+def check(status, where):
+    if status != ARIA_OK:
+        raise AriaError(status, where)
+
+
+def synth_frame_pair(seed, width=640, height=480):
+    """Synthetic frame pair of SURVEY.md 8(d): B shows A's content moved by (+3, +2) px."""
+    a = np.empty((height, width), np.uint8)
+    b = np.empty((height, width), np.uint8)
+    check(load_library().aria_synth_frame_pair(seed, width, height, a.ctypes.data, b.ctypes.data), "aria_synth_frame_pair")
+    return a, b
+
+
+def synth_sequence(seed0, n_pairs, width=640, height=480, out=None, n_threads=None):
+    """2*n_pairs frames A(seed0), B(seed0), A(seed0+1), ... as one (2*n_pairs, H, W) uint8 array."""
+    if out is None:
+        out = np.empty((2 * n_pairs, height, width), np.uint8)
+    assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size == 2 * n_pairs * height * width
+    if n_threads is None:
+        n_threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    check(load_library().aria_synth_sequence(seed0, n_pairs, width, height, out.ctypes.data, n_threads), "aria_synth_sequence")
+    return out

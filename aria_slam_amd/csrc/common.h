@@ -1,0 +1,41 @@
+// Shared host-side helpers for the C-ABI implementation (not part of the public interface).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "aria_orb_hip.h"
+
+namespace aria {
+
+// thread-local text of the last HIP failure, surfaced through aria_last_hip_error()
+char* last_hip_error_buf();
+
+inline int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    std::snprintf(last_hip_error_buf(), 256, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return e == hipErrorOutOfMemory ? ARIA_E_OOM : ARIA_E_NO_DEVICE;
+}
+
+#define ARIA_HIP(call)                                                          \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return aria::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// deferred error bits written by kernels
+enum : int {
+    ERRBIT_CAND_OVERFLOW = 1,   // FAST candidate list of some (frame, level) exceeded cand_cap
+    ERRBIT_SORT_OVERFLOW = 2,   // more candidates tied at the first cut than the LDS sort holds
+    ERRBIT_SEL_OVERFLOW = 4,    // more keypoints tied at the Harris cut than sel_cap
+    ERRBIT_KPCAP = 8,           // caller's kp_cap smaller than a frame's result
+    ERRBIT_MATCHCAP = 16        // caller's match_cap smaller than a pair's result
+};
+
+inline int errbits_to_status(int bits) {
+    if (bits & (ERRBIT_CAND_OVERFLOW | ERRBIT_SORT_OVERFLOW | ERRBIT_SEL_OVERFLOW)) return ARIA_E_OVERFLOW;
+    if (bits & (ERRBIT_KPCAP | ERRBIT_MATCHCAP)) return ARIA_E_OUTPUT_TOO_SMALL;
+    return ARIA_OK;
+}
+
+}  // namespace aria

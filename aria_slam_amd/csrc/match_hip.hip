@@ -1,0 +1,351 @@
+// Brute-force Hamming kNN-2 matcher for 256-bit descriptors on gfx950 + its C-ABI.
+// Replaces the reference's CudaMatcher (src/adapters/gpu/CudaMatcher.cpp:28-68, cv::cuda BFMatcher::knnMatch(k=2)
+// + Lowe ratio) and the legacy loop-closure scan (src/legacy/LoopClosure.cpp:72-114, cv::BFMatcher CPU).
+// Semantics follow CPU cv::BFMatcher (OpenCV 4.9.0 batch_distance.cpp): in-order scan with strict '<'
+// insertion, i.e. the two smallest (distance, train index) pairs in lexicographic order.
+//
+// Not HBM-bound (160 KB of compulsory traffic per 2000x2000 pair): it is VALU-integer work, 8 x (v_xor +
+// v_bcnt_u32_b32 accumulate) per descriptor pair. One lane owns one query (8 dwords in VGPRs); train descriptors
+// are staged through LDS in tiles of 256 and read as wave-uniform (broadcast) ds_read_b128; the running top-2
+// is kept as two packed keys (distance << 16 | train index) so ties resolve to the lower index for free.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+using namespace aria;
+
+namespace {
+
+constexpr int kMatchTile = 256;
+
+template <int MODE>   // 0: store the two keys per query; 1: count queries passing the double-precision ratio test
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed,
+                                              const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed,
+                                              int64_t q_stride, int64_t t_stride, uint2* __restrict__ keys, int maxq,
+                                              double ratio, int* __restrict__ good) {
+    __shared__ uint4 s_t[kMatchTile * 2];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.y;
+    const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
+    const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
+    if ((int)blockIdx.x * 256 >= nq) return;
+    const int qi = blockIdx.x * 256 + tid;
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (int64_t)pair * q_stride);
+    const uint4* tp = reinterpret_cast<const uint4*>(t + (int64_t)pair * t_stride);
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (qi < nq) { qa = qp[2 * qi]; qb = qp[2 * qi + 1]; }
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    for (int t0 = 0; t0 < nt; t0 += kMatchTile) {
+        __syncthreads();
+        if (t0 + tid < nt) {
+            s_t[2 * tid] = tp[2 * (t0 + tid)];
+            s_t[2 * tid + 1] = tp[2 * (t0 + tid) + 1];
+        }
+        __syncthreads();
+        const int cnt = min(kMatchTile, nt - t0);
+        for (int j = 0; j < cnt; j++) {
+            const uint4 a = s_t[2 * j], b = s_t[2 * j + 1];
+            int d = __popc(qa.x ^ a.x);
+            d += __popc(qa.y ^ a.y);
+            d += __popc(qa.z ^ a.z);
+            d += __popc(qa.w ^ a.w);
+            d += __popc(qb.x ^ b.x);
+            d += __popc(qb.y ^ b.y);
+            d += __popc(qb.z ^ b.z);
+            d += __popc(qb.w ^ b.w);
+            const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + j);
+            k1 = min(k1, max(k0, key));
+            k0 = min(k0, key);
+        }
+    }
+    if (MODE == 0) {
+        if (qi < nq) keys[(int64_t)pair * maxq + qi] = make_uint2(k0, k1);
+    } else {
+        // LoopClosure.cpp:92  m[0].distance < 0.7 * m[1].distance  (float distances, double arithmetic)
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        bool ok = false;
+        if (qi < nq && k1 != 0xFFFFFFFFu) ok = (double)(float)(k0 >> 16) < ratio * (double)(float)(k1 >> 16);
+        const unsigned long long m = __ballot(ok);
+        if ((tid & 63) == 0 && m) atomicAdd(&s_cnt, __popcll(m));
+        __syncthreads();
+        if (tid == 0 && s_cnt) atomicAdd(&good[pair], s_cnt);
+    }
+}
+
+// CudaMatcher.cpp:59-67: fp32 Lowe test, matches appended in query order. One workgroup per pair; the ordered
+// compaction uses wave ballots + popcount prefixes.
+__global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__ keys, const int* __restrict__ nq_arr,
+                                                       int nq_fixed, int maxq, float ratio,
+                                                       aria_match* __restrict__ out, int* __restrict__ nout, int cap,
+                                                       int* __restrict__ err) {
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pair = blockIdx.x;
+    const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
+    const uint2* kk = keys + (int64_t)pair * maxq;
+    aria_match* o = out + (int64_t)pair * cap;
+    int base = 0;
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int qi = q0 + tid;
+        bool ok = false;
+        uint2 k = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (qi < nq) {
+            k = kk[qi];
+            if (ratio == 0.0f) ok = k.x != 0xFFFFFFFFu;   // IMatcher.hpp:18 "0.0 = disabled"
+            else ok = k.y != 0xFFFFFFFFu && (float)(k.x >> 16) < ratio * (float)(k.y >> 16);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; w++) off += s_w[w];
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) {
+            if (off < cap) {
+                aria_match mm;
+                mm.query_idx = qi;
+                mm.train_idx = (int)(k.x & 0xFFFFu);
+                mm.distance = (float)(k.x >> 16);
+                o[off] = mm;
+            } else {
+                atomicOr(err, ERRBIT_MATCHCAP);
+            }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) nout[pair] = min(base, cap);
+}
+
+__global__ void k_unpack_knn(const uint2* __restrict__ keys, int nq, int* __restrict__ idx, int* __restrict__ dist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const uint2 k = keys[i];
+    idx[2 * i] = k.x == 0xFFFFFFFFu ? -1 : (int)(k.x & 0xFFFFu);
+    dist[2 * i] = k.x == 0xFFFFFFFFu ? INT_MAX : (int)(k.x >> 16);
+    idx[2 * i + 1] = k.y == 0xFFFFFFFFu ? -1 : (int)(k.y & 0xFFFFu);
+    dist[2 * i + 1] = k.y == 0xFFFFFFFFu ? INT_MAX : (int)(k.y >> 16);
+}
+
+}  // namespace
+
+struct aria_matcher_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int max_query = 0, max_train = 0;
+    uint2* d_keys = nullptr;        // grow-only scratch: [n_pairs][maxq]
+    size_t keys_cap = 0;
+    int* d_err = nullptr;
+    // host-buffer path
+    uint8_t* d_q = nullptr;
+    uint8_t* d_t = nullptr;
+    aria_match* d_m = nullptr;
+    int* d_n = nullptr;             // [0] nmatches
+    int* d_idx = nullptr;           // 2*max_query idx + 2*max_query dist
+    uint8_t* h_stage = nullptr;     // pinned: q | t
+    aria_match* h_m = nullptr;      // pinned
+    int* h_n = nullptr;             // pinned [0] n, [1] err
+    int* h_idx = nullptr;           // pinned
+};
+
+namespace {
+
+int ensure_keys(aria_matcher_s* m, size_t entries) {
+    if (entries <= m->keys_cap) return ARIA_OK;
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    if (m->d_keys) hipFree(m->d_keys);
+    m->d_keys = nullptr;
+    m->keys_cap = 0;
+    ARIA_HIP(hipMalloc(&m->d_keys, entries * sizeof(uint2)));
+    m->keys_cap = entries;
+    return ARIA_OK;
+}
+
+void matcher_free(aria_matcher_s* m) {
+    hipFree(m->d_keys); hipFree(m->d_err); hipFree(m->d_q); hipFree(m->d_t); hipFree(m->d_m); hipFree(m->d_n);
+    hipFree(m->d_idx);
+    if (m->h_stage) hipHostFree(m->h_stage);
+    if (m->h_m) hipHostFree(m->h_m);
+    if (m->h_n) hipHostFree(m->h_n);
+    if (m->h_idx) hipHostFree(m->h_idx);
+}
+
+int matcher_alloc(aria_matcher_s* m) {
+    const size_t nq = (size_t)std::max(m->max_query, 1), nt = (size_t)std::max(m->max_train, 1);
+    ARIA_HIP(hipMalloc(&m->d_err, sizeof(int)));
+    ARIA_HIP(hipMemset(m->d_err, 0, sizeof(int)));
+    ARIA_HIP(hipMalloc(&m->d_q, nq * 32));
+    ARIA_HIP(hipMalloc(&m->d_t, nt * 32));
+    ARIA_HIP(hipMalloc(&m->d_m, nq * sizeof(aria_match)));
+    ARIA_HIP(hipMalloc(&m->d_n, sizeof(int)));
+    ARIA_HIP(hipMalloc(&m->d_idx, nq * 4 * sizeof(int)));
+    ARIA_HIP(hipHostMalloc(&m->h_stage, (nq + nt) * 32));
+    ARIA_HIP(hipHostMalloc(&m->h_m, nq * sizeof(aria_match)));
+    ARIA_HIP(hipHostMalloc(&m->h_n, 2 * sizeof(int)));
+    ARIA_HIP(hipHostMalloc(&m->h_idx, nq * 4 * sizeof(int)));
+    return ensure_keys(m, nq);
+}
+
+int upload_pair(aria_matcher_s* m, const uint8_t* q, int nq, const uint8_t* t, int nt) {
+    std::memcpy(m->h_stage, q, (size_t)nq * 32);
+    std::memcpy(m->h_stage + (size_t)m->max_query * 32, t, (size_t)nt * 32);
+    ARIA_HIP(hipMemcpyAsync(m->d_q, m->h_stage, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    ARIA_HIP(hipMemcpyAsync(m->d_t, m->h_stage + (size_t)m->max_query * 32, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+    return ARIA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void aria_matcher_default_config(aria_matcher_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int)sizeof(aria_matcher_config);
+    c->max_query = 4096;
+    c->max_train = 4096;
+}
+
+int aria_matcher_create(const aria_matcher_config* c, aria_matcher_t* out) {
+    if (!c || !out || c->struct_size != (int)sizeof(aria_matcher_config)) return ARIA_E_INVALID;
+    if (c->max_query < 1 || c->max_train < 1 || c->max_train > 65535 || c->max_query > (1 << 24)) return ARIA_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    ARIA_HIP(hipGetDeviceCount(&ndev));
+    if (c->device < 0 || c->device >= ndev) {
+        std::snprintf(last_hip_error_buf(), 256, "device %d not present (%d devices)", c->device, ndev);
+        return ARIA_E_NO_DEVICE;
+    }
+    ARIA_HIP(hipSetDevice(c->device));
+    aria_matcher_s* m = new (std::nothrow) aria_matcher_s();
+    if (!m) return ARIA_E_OOM;
+    m->device = c->device;
+    m->max_query = c->max_query;
+    m->max_train = c->max_train;
+    if (c->stream) {
+        m->stream = (hipStream_t)c->stream;
+    } else {
+        hipError_t e = hipStreamCreate(&m->stream);
+        if (e != hipSuccess) { delete m; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+        m->owns_stream = true;
+    }
+    int rc = matcher_alloc(m);
+    if (rc != ARIA_OK) { aria_matcher_destroy(m); return rc; }
+    *out = m;
+    return ARIA_OK;
+}
+
+void aria_matcher_destroy(aria_matcher_t m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    matcher_free(m);
+    if (m->owns_stream && m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+void* aria_matcher_stream(aria_matcher_t m) { return m ? (void*)m->stream : nullptr; }
+
+int aria_matcher_sync(aria_matcher_t m) {
+    if (!m) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(m->device));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    int bits = 0;
+    ARIA_HIP(hipMemcpy(&bits, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (bits) ARIA_HIP(hipMemset(m->d_err, 0, sizeof(int)));
+    return errbits_to_status(bits);
+}
+
+int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
+                       aria_match* matches, int cap, int* n_out) {
+    if (!m || !n_out || nq < 0 || nt < 0 || cap < 0) return ARIA_E_INVALID;
+    *n_out = 0;
+    if (nq == 0 || nt == 0) return ARIA_OK;   // CudaMatcher.cpp:35-37
+    if (!q || !t) return ARIA_E_INVALID;
+    if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(m->device));
+    int rc = upload_pair(m, q, nq, t, nt);
+    if (rc != ARIA_OK) return rc;
+    hipLaunchKernelGGL(k_knn2<0>, dim3((nq + 255) / 256, 1), dim3(256), 0, m->stream, m->d_q, nullptr, nq, m->d_t,
+                       nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys, m->max_query, 0.0, nullptr);
+    hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
+                       m->d_m, m->d_n, m->max_query, m->d_err);
+    ARIA_HIP(hipGetLastError());
+    ARIA_HIP(hipMemcpyAsync(m->h_n, m->d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipMemcpyAsync(m->h_m, m->d_m, sizeof(aria_match) * (size_t)nq, hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    const int n = m->h_n[0];
+    *n_out = n;
+    if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
+    if (n > 0) {
+        if (!matches) return ARIA_E_INVALID;
+        std::memcpy(matches, m->h_m, sizeof(aria_match) * (size_t)n);
+    }
+    return ARIA_OK;
+}
+
+int aria_matcher_knn2(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist) {
+    if (!m || nq < 0 || nt < 0) return ARIA_E_INVALID;
+    if (nq == 0) return ARIA_OK;
+    if (!q || !idx || !dist || (nt > 0 && !t)) return ARIA_E_INVALID;
+    if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(m->device));
+    int rc = upload_pair(m, q, nq, t ? t : q, nt);
+    if (rc != ARIA_OK) return rc;
+    hipLaunchKernelGGL(k_knn2<0>, dim3((nq + 255) / 256, 1), dim3(256), 0, m->stream, m->d_q, nullptr, nq, m->d_t,
+                       nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys, m->max_query, 0.0, nullptr);
+    hipLaunchKernelGGL(k_unpack_knn, dim3((nq + 255) / 256), dim3(256), 0, m->stream, m->d_keys, nq, m->d_idx,
+                       m->d_idx + 2 * (size_t)m->max_query);
+    ARIA_HIP(hipGetLastError());
+    ARIA_HIP(hipMemcpyAsync(m->h_idx, m->d_idx, sizeof(int) * 4 * (size_t)m->max_query, hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    std::memcpy(idx, m->h_idx, sizeof(int) * 2 * (size_t)nq);
+    std::memcpy(dist, m->h_idx + 2 * (size_t)m->max_query, sizeof(int) * 2 * (size_t)nq);
+    return ARIA_OK;
+}
+
+int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, const int* d_nq, const uint8_t* d_train,
+                                    const int* d_nt, int n_pairs, int64_t desc_stride, float ratio,
+                                    aria_match* d_matches, int* d_nmatches, int match_cap) {
+    if (!m || !d_query || !d_nq || !d_train || !d_nt || !d_matches || !d_nmatches || n_pairs < 0 || match_cap < 1 ||
+        desc_stride < 32 || (desc_stride & 31))
+        return ARIA_E_INVALID;
+    if (n_pairs == 0) return ARIA_OK;
+    const int64_t maxq = desc_stride / 32;
+    if (maxq > 65535) return ARIA_E_TOO_LARGE;   // train index is packed in 16 bits
+    ARIA_HIP(hipSetDevice(m->device));
+    int rc = ensure_keys(m, (size_t)n_pairs * (size_t)maxq);
+    if (rc != ARIA_OK) return rc;
+    hipLaunchKernelGGL(k_knn2<0>, dim3((unsigned)((maxq + 255) / 256), n_pairs), dim3(256), 0, m->stream, d_query, d_nq,
+                       0, d_train, d_nt, 0, desc_stride, desc_stride, m->d_keys, (int)maxq, 0.0, nullptr);
+    hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
+                       d_matches, d_nmatches, match_cap, m->d_err);
+    ARIA_HIP(hipGetLastError());
+    return ARIA_OK;
+}
+
+int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int nq, const uint8_t* d_db,
+                                 const int* d_kf_counts, int n_kf, int64_t desc_stride, double ratio, int* d_good) {
+    if (!m || !d_query || !d_db || !d_kf_counts || !d_good || nq < 0 || n_kf < 0 || desc_stride < 32 || (desc_stride & 31))
+        return ARIA_E_INVALID;
+    if (desc_stride / 32 > 65535) return ARIA_E_TOO_LARGE;
+    if (n_kf == 0) return ARIA_OK;
+    ARIA_HIP(hipSetDevice(m->device));
+    ARIA_HIP(hipMemsetAsync(d_good, 0, sizeof(int) * (size_t)n_kf, m->stream));
+    if (nq == 0) return ARIA_OK;
+    hipLaunchKernelGGL(k_knn2<1>, dim3((nq + 255) / 256, n_kf), dim3(256), 0, m->stream, d_query, nullptr, nq, d_db,
+                       d_kf_counts, 0, (int64_t)0, desc_stride, nullptr, 0, ratio, d_good);
+    ARIA_HIP(hipGetLastError());
+    return ARIA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+// C-ABI of the extractor (include/aria_orb_hip.h): handle lifetime, scratch allocation, host-buffer and
+// device-resident entry points. Replaces the body of the reference's OrbCudaExtractor
+// (src/adapters/gpu/OrbCudaExtractor.cpp) -- there the work is cv::cuda::ORB calls, here it is the kernels in
+// orb_kernels.hip. No CPU fallback exists: without a HIP device every entry point fails with ARIA_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "orb_kernels.h"
+
+namespace aria {
+char* last_hip_error_buf() {
+    static thread_local char buf[256] = {0};
+    return buf;
+}
+}  // namespace aria
+
+using namespace aria;
+
+struct aria_orb_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 32;
+
+    Plan plan{};            // plan of the most recent (width, height)
+    bool plan_valid = false;
+    std::vector<uint32_t> tab_host;
+    DeviceScratch D{};
+    int kp_cap = 0;         // rows of the internal single-frame output buffers
+
+    // single-frame host path
+    uint8_t* d_img = nullptr;
+    uint8_t* h_img = nullptr;          // pinned
+    aria_keypoint* d_kps = nullptr;
+    uint8_t* d_desc = nullptr;
+    int* d_count = nullptr;
+    aria_keypoint* h_kps = nullptr;    // pinned
+    uint8_t* h_desc = nullptr;         // pinned
+    int* h_count = nullptr;            // pinned: [0] count, [1] err bits
+    bool pending = false;
+
+    FrameSrc last_src{};
+    bool have_last = false;
+};
+
+namespace {
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+void free_scratch(aria_orb_s* h) {
+    hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand); hipFree(h->D.cand_cnt);
+    hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.err);
+    hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_count);
+    if (h->h_img) hipHostFree(h->h_img);
+    if (h->h_kps) hipHostFree(h->h_kps);
+    if (h->h_desc) hipHostFree(h->h_desc);
+    if (h->h_count) hipHostFree(h->h_count);
+    h->D = DeviceScratch{};
+    h->d_img = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_count = nullptr;
+    h->h_img = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_count = nullptr;
+}
+
+// Size everything for (max_w, max_h, max_features, max_batch). Level sizes are monotone in width/height, so a
+// plan for any smaller image fits.
+int alloc_scratch(aria_orb_s* h) {
+    Plan mp;
+    int64_t tabn = plan_tab_entries(h->max_w, h->max_h) + 64;
+    h->tab_host.assign((size_t)tabn, 0);
+    int used = 0;
+    int rc = build_plan(h->max_w, h->max_h, h->max_features, h->cand_cap_scale, h->tie_mode, &mp, h->tab_host.data(),
+                        (int)tabn, &used);
+    if (rc != ARIA_OK) return rc;
+    const size_t B = (size_t)h->max_batch;
+    h->kp_cap = mp.sel_frame_entries;
+    ARIA_HIP(hipMalloc(&h->D.raw, std::max<size_t>(mp.raw_frame_bytes * B, 256)));
+    ARIA_HIP(hipMalloc(&h->D.blur, std::max<size_t>(mp.blur_frame_bytes * B, 256)));
+    ARIA_HIP(hipMalloc(&h->D.cand, sizeof(uint32_t) * (size_t)mp.cand_frame_entries * B));
+    ARIA_HIP(hipMalloc(&h->D.cand_cnt, sizeof(int) * kLevels * B));
+    ARIA_HIP(hipMalloc(&h->D.sel, sizeof(uint2) * (size_t)mp.sel_frame_entries * B));
+    ARIA_HIP(hipMalloc(&h->D.sel_cnt, sizeof(int) * kLevels * B));
+    ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
+    ARIA_HIP(hipMalloc(&h->D.err, sizeof(int)));
+    ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
+    const size_t img_bytes = (size_t)align_up(h->max_w, 4) * h->max_h;
+    ARIA_HIP(hipMalloc(&h->d_img, img_bytes));
+    ARIA_HIP(hipHostMalloc(&h->h_img, img_bytes));
+    ARIA_HIP(hipMalloc(&h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
+    ARIA_HIP(hipMalloc(&h->d_desc, 32 * (size_t)h->kp_cap));
+    ARIA_HIP(hipMalloc(&h->d_count, sizeof(int)));
+    ARIA_HIP(hipHostMalloc(&h->h_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
+    ARIA_HIP(hipHostMalloc(&h->h_desc, 32 * (size_t)h->kp_cap));
+    ARIA_HIP(hipHostMalloc(&h->h_count, 2 * sizeof(int)));
+    h->plan_valid = false;
+    return ARIA_OK;
+}
+
+int ensure_plan(aria_orb_s* h, int w, int ht) {
+    if (w > h->max_w || ht > h->max_h) return ARIA_E_TOO_LARGE;
+    if (h->plan_valid && h->plan.width == w && h->plan.height == ht && h->plan.nfeatures == h->max_features)
+        return ARIA_OK;
+    int used = 0;
+    int rc = build_plan(w, ht, h->max_features, h->cand_cap_scale, h->tie_mode, &h->plan, h->tab_host.data(),
+                        (int)h->tab_host.size(), &used);
+    if (rc != ARIA_OK) return rc;
+    if (used > 0)
+        ARIA_HIP(hipMemcpyAsync(h->D.tab, h->tab_host.data(), sizeof(uint32_t) * (size_t)used, hipMemcpyHostToDevice,
+                                h->stream));
+    h->plan_valid = true;
+    return ARIA_OK;
+}
+
+int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, int stride) {
+    if (!image || stride < width) return ARIA_E_INVALID;
+    int rc = ensure_plan(h, width, height);
+    if (rc != ARIA_OK) return rc;
+    const int pitch = align_up(width, 4);
+    for (int y = 0; y < height; y++) std::memcpy(h->h_img + (size_t)y * pitch, image + (size_t)y * stride, (size_t)width);
+    ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, (size_t)pitch * height, hipMemcpyHostToDevice, h->stream));
+    FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1};
+    h->last_src = S;
+    h->have_last = true;
+    launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream);
+    ARIA_HIP(hipGetLastError());
+    ARIA_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, 32 * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipMemcpyAsync(&h->h_count[0], h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipMemcpyAsync(&h->h_count[1], h->D.err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipMemsetAsync(h->D.err, 0, sizeof(int), h->stream));
+    return ARIA_OK;
+}
+
+int finish_single(aria_orb_s* h, aria_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    ARIA_HIP(hipStreamSynchronize(h->stream));
+    const int errbits = h->h_count[1];
+    int st = errbits_to_status(errbits & ~ERRBIT_KPCAP);
+    if (st != ARIA_OK) { if (n_out) *n_out = 0; return st; }
+    const int n = h->h_count[0];
+    if (n_out) *n_out = n;
+    if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
+    if (n > 0) {
+        if (!kps || !desc) return ARIA_E_INVALID;
+        std::memcpy(kps, h->h_kps, sizeof(aria_keypoint) * (size_t)n);
+        std::memcpy(desc, h->h_desc, 32 * (size_t)n);
+    }
+    return ARIA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* aria_status_string(int s) {
+    switch (s) {
+        case ARIA_OK: return "ok";
+        case ARIA_E_INVALID: return "invalid argument";
+        case ARIA_E_NO_DEVICE: return "no usable HIP device or HIP runtime error";
+        case ARIA_E_OOM: return "out of memory";
+        case ARIA_E_TOO_LARGE: return "image larger than the handle was created for";
+        case ARIA_E_OUTPUT_TOO_SMALL: return "output capacity too small";
+        case ARIA_E_OVERFLOW: return "internal candidate/sort buffer overflow";
+        case ARIA_E_BUSY: return "an asynchronous extract is already pending";
+        case ARIA_E_NOT_PENDING: return "no asynchronous extract pending";
+        default: return "unknown status";
+    }
+}
+
+int aria_abi_version(void) { return ARIA_ORB_HIP_ABI_VERSION; }
+const char* aria_last_hip_error(void) { return last_hip_error_buf(); }
+
+void aria_orb_default_config(aria_orb_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int)sizeof(aria_orb_config);
+    c->device = 0;
+    c->stream = nullptr;
+    c->max_width = 640;
+    c->max_height = 480;
+    c->max_features = 1000;   // reference include/adapters/gpu/OrbCudaExtractor.hpp:12
+    c->max_batch = 1;
+    c->blur_tie_mode = 1;
+    c->cand_cap_scale = 0;
+}
+
+int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
+    if (!c || !out || c->struct_size != (int)sizeof(aria_orb_config)) return ARIA_E_INVALID;
+    if (c->max_width < 16 || c->max_height < 16 || c->max_width > kMaxDim || c->max_height > kMaxDim ||
+        c->max_features < 0 || c->max_features > 65536 || c->max_batch < 1)
+        return ARIA_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    ARIA_HIP(hipGetDeviceCount(&ndev));
+    if (c->device < 0 || c->device >= ndev) {
+        std::snprintf(last_hip_error_buf(), 256, "device %d not present (%d devices)", c->device, ndev);
+        return ARIA_E_NO_DEVICE;
+    }
+    ARIA_HIP(hipSetDevice(c->device));
+    aria_orb_s* h = new (std::nothrow) aria_orb_s();
+    if (!h) return ARIA_E_OOM;
+    h->device = c->device;
+    h->max_w = c->max_width;
+    h->max_h = c->max_height;
+    h->max_features = c->max_features;
+    h->max_batch = c->max_batch;
+    h->tie_mode = c->blur_tie_mode ? 1 : 0;
+    h->cand_cap_scale = c->cand_cap_scale > 0 ? c->cand_cap_scale : 32;
+    if (c->stream) {
+        h->stream = (hipStream_t)c->stream;
+    } else {
+        hipError_t e = hipStreamCreate(&h->stream);
+        if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+        h->owns_stream = true;
+    }
+    int rc = alloc_scratch(h);
+    if (rc != ARIA_OK) { aria_orb_destroy(h); return rc; }
+    *out = h;
+    return ARIA_OK;
+}
+
+void aria_orb_destroy(aria_orb_t h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    free_scratch(h);
+    if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int aria_orb_set_max_features(aria_orb_t h, int n) {
+    if (!h || n < 0 || n > 65536) return ARIA_E_INVALID;
+    if (h->pending) return ARIA_E_BUSY;
+    if (n == h->max_features) return ARIA_OK;
+    ARIA_HIP(hipSetDevice(h->device));
+    ARIA_HIP(hipStreamSynchronize(h->stream));
+    const int old = h->max_features;
+    free_scratch(h);
+    h->max_features = n;
+    int rc = alloc_scratch(h);
+    if (rc != ARIA_OK) {
+        free_scratch(h);
+        h->max_features = old;
+        alloc_scratch(h);
+    }
+    h->have_last = false;
+    return rc;
+}
+
+int aria_orb_get_max_features(aria_orb_t h) { return h ? h->max_features : ARIA_E_INVALID; }
+int aria_orb_kp_capacity(aria_orb_t h) { return h ? h->kp_cap : ARIA_E_INVALID; }
+void* aria_orb_stream(aria_orb_t h) { return h ? (void*)h->stream : nullptr; }
+
+int aria_orb_extract(aria_orb_t h, const uint8_t* image, int width, int height, int stride,
+                     aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out) {
+    if (!h || cap < 0) return ARIA_E_INVALID;
+    if (h->pending) return ARIA_E_BUSY;
+    ARIA_HIP(hipSetDevice(h->device));
+    int rc = enqueue_single(h, image, width, height, stride);
+    if (rc != ARIA_OK) return rc;
+    return finish_single(h, keypoints, descriptors, cap, n_out);
+}
+
+int aria_orb_extract_async(aria_orb_t h, const uint8_t* image, int width, int height, int stride) {
+    if (!h) return ARIA_E_INVALID;
+    if (h->pending) return ARIA_E_BUSY;
+    ARIA_HIP(hipSetDevice(h->device));
+    int rc = enqueue_single(h, image, width, height, stride);
+    if (rc == ARIA_OK) h->pending = true;
+    return rc;
+}
+
+int aria_orb_sync(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out) {
+    if (!h || cap < 0) return ARIA_E_INVALID;
+    if (!h->pending) return ARIA_E_NOT_PENDING;
+    ARIA_HIP(hipSetDevice(h->device));
+    h->pending = false;
+    return finish_single(h, keypoints, descriptors, cap, n_out);
+}
+
+int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_frames, int width, int height,
+                                  int64_t frame_stride, int row_stride, aria_keypoint* d_keypoints,
+                                  uint8_t* d_descriptors, int* d_counts, int kp_cap) {
+    if (!h || !d_images || !d_keypoints || !d_descriptors || !d_counts || n_frames < 0 || kp_cap < 1 ||
+        row_stride < width || frame_stride < (int64_t)row_stride * (height - 1) + width)
+        return ARIA_E_INVALID;
+    if (h->pending) return ARIA_E_BUSY;
+    ARIA_HIP(hipSetDevice(h->device));
+    int rc = ensure_plan(h, width, height);
+    if (rc != ARIA_OK) return rc;
+    const int aligned4 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
+    for (int f0 = 0; f0 < n_frames; f0 += h->max_batch) {
+        const int nf = std::min(h->max_batch, n_frames - f0);
+        FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4};
+        if (f0 == 0) { h->last_src = S; h->have_last = true; }
+        launch_extract_chunk(h->plan, S, h->D, nf, d_keypoints + (int64_t)f0 * kp_cap,
+                             d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream);
+    }
+    ARIA_HIP(hipGetLastError());
+    return ARIA_OK;
+}
+
+int aria_orb_check(aria_orb_t h) {
+    if (!h) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(h->device));
+    ARIA_HIP(hipStreamSynchronize(h->stream));
+    int bits = 0;
+    ARIA_HIP(hipMemcpy(&bits, h->D.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (bits) ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
+    return errbits_to_status(bits);
+}
+
+int aria_orb_level_info(aria_orb_t h, int width, int height, int level, int* lw, int* lh, int* quota, float* scale) {
+    if (!h || level < 0 || level >= kLevels) return ARIA_E_INVALID;
+    Plan p;
+    std::vector<uint32_t> tab((size_t)plan_tab_entries(width, height) + 64);
+    int used = 0;
+    int rc = build_plan(width, height, h->max_features, h->cand_cap_scale, h->tie_mode, &p, tab.data(), (int)tab.size(), &used);
+    if (rc != ARIA_OK) return rc;
+    if (lw) *lw = p.lv[level].w;
+    if (lh) *lh = p.lv[level].h;
+    if (quota) *quota = p.lv[level].quota;
+    if (scale) *scale = p.lv[level].scale;
+    return ARIA_OK;
+}
+
+int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* host_out) {
+    if (!h || !host_out || level < 0 || level >= kLevels || !h->plan_valid || !h->have_last) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(h->device));
+    ARIA_HIP(hipStreamSynchronize(h->stream));
+    const LevelGeom& g = h->plan.lv[level];
+    const uint8_t* src;
+    size_t spitch;
+    if (blurred) { src = h->D.blur + g.blur_off; spitch = (size_t)g.pitch; }
+    else if (level == 0) { src = h->last_src.img; spitch = (size_t)h->last_src.row_stride; }
+    else { src = h->D.raw + g.raw_off; spitch = (size_t)g.pitch; }
+    ARIA_HIP(hipMemcpy2D(host_out, (size_t)g.w, src, spitch, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost));
+    return ARIA_OK;
+}
+
+int aria_orb_algorithmic_bytes(aria_orb_t h, int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused) {
+    if (!h) return ARIA_E_INVALID;
+    Plan p;
+    std::vector<uint32_t> tab((size_t)plan_tab_entries(width, height) + 64);
+    int used = 0;
+    int rc = build_plan(width, height, h->max_features, h->cand_cap_scale, h->tie_mode, &p, tab.data(), (int)tab.size(), &used);
+    if (rc != ARIA_OK) return rc;
+    const int64_t P = p.pixels_total;
+    const int64_t p0 = (int64_t)p.lv[0].w * p.lv[0].h, p7 = (int64_t)p.lv[kLevels - 1].w * p.lv[kLevels - 1].h;
+    if (b_extract) *b_extract = 5 * P - p0 - p7 + 56ll * n_keypoints;
+    if (b_fused) *b_fused = 2 * P + 56ll * n_keypoints;
+    return ARIA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// Kernel-launch interface between the C-ABI host code (orb_api.hip) and the kernels (orb_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "aria_orb_hip.h"
+#include "orb_plan.h"
+
+namespace aria {
+
+// Where level 0 lives: the caller's images, read in place.
+struct FrameSrc {
+    const uint8_t* img;     // frame 0 of the chunk
+    int64_t frame_stride;   // bytes between frames
+    int row_stride;         // bytes between rows
+    int aligned4;           // base, frame_stride and row_stride all multiples of 4 -> dword loads allowed
+};
+
+// Per-chunk device scratch owned by the extractor handle (HBM layout: DESIGN.md "Data layout").
+struct DeviceScratch {
+    uint8_t* raw;        // [max_batch][raw_frame_bytes]   pyramid levels 1..7, un-blurred
+    uint8_t* blur;       // [max_batch][blur_frame_bytes]  pyramid levels 0..7, blurred
+    uint32_t* cand;      // [max_batch][cand_frame_entries] FAST candidates x:11|y:11|score:8
+    int* cand_cnt;       // [max_batch][8]
+    uint2* sel;          // [max_batch][sel_frame_entries]  (x | y<<16, harris bits), canonical order per level
+    int* sel_cnt;        // [max_batch][8]
+    uint32_t* tab;       // resize coefficient tables (ofs | c1 << 16)
+    int* err;            // deferred error bits
+};
+
+void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
+                          aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st);
+
+}  // namespace aria

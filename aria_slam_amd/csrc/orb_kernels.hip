@@ -1,0 +1,554 @@
+// HIP kernels of the ORB extractor for gfx950 (MI355X). Wave = 64 lanes throughout.
+//
+// Stage map (algorithm = CPU cv::ORB of OpenCV 4.9.0):
+//   k_resize      a6.1  pyramid level l from level l-1, INTER_LINEAR_EXACT fixed point (8+8 fractional bits)
+//   k_fast_blur   a6.2  FAST-9/16 score + 3x3 strict-max NMS + 31-px border filter -> candidate list
+//                 a6.7  7x7 sigma-2 Gaussian (8-bit fixed-point separable) of the same LDS tile -> blurred level
+//   k_select      a6.3  retainBest(2*quota) by FAST score (256-bin histogram cut, ties kept)
+//                 a6.4  Harris response (block 7, k 0.04) of the survivors
+//                 a6.5  retainBest(quota) by Harris (LDS bitonic sort, ties kept) -> canonical order
+//   k_describe    a6.6  intensity-centroid angle (one wave per keypoint, integer moments, fastAtan2)
+//                 a6.8  256-bit rBRIEF: lane i evaluates tests i, i+64, i+128, i+192; four 64-bit ballots are
+//                       exactly the 32 descriptor bytes (LSB-first)
+// All of it is HBM/LDS/VALU-integer work; nothing here is a dense contraction, so no MFMA.
+// Float stages are compiled with -ffp-contract=off so that they round exactly like the SSE3-baseline
+// OpenCV build the CPU reference path uses (no FMA).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "common.h"
+#include "orb_kernels.h"
+
+namespace aria {
+
+__device__ const signed char kPattern31[1024] = {
+#include "orb_pattern_31.inc"
+};
+
+// end-of-row table of the radius-15 disc (orb.cpp computeKeyPoints umax; verified against the host
+// computation in tests/test_host_logic.py)
+#define ARIA_UMAX_LIST {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3}
+
+__device__ __forceinline__ const uint8_t* raw_level_ptr(const Plan& P, const FrameSrc& S, const uint8_t* raw,
+                                                        int frame, int l, int& pitch) {
+    if (l == 0) {
+        pitch = S.row_stride;
+        return S.img + (int64_t)frame * S.frame_stride;
+    }
+    pitch = P.lv[l].pitch;
+    return raw + (int64_t)frame * P.raw_frame_bytes + P.lv[l].raw_off;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    // BORDER_REFLECT_101; inputs here never lie more than one period outside, clamp guards tiny levels
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return min(max(i, 0), n - 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a6.1  resize.cpp resize_bitExact<uchar, interpolationLinear>: H = c0*p[o] + c1*p[o+1] (exact, 8 frac bits),
+//       out = (cy0*H0 + cy1*H1 + 32768) >> 16. One thread = 4 adjacent output pixels = one dword store.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
+                                                const uint32_t* __restrict__ tab, int l) {
+    const LevelGeom g = P.lv[l];
+    const int frame = blockIdx.y;
+    const int groups = g.pitch >> 2;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= groups * g.h) return;
+    const int dy = gid / groups, gx = gid - dy * groups;
+    int spitch;
+    const uint8_t* src = raw_level_ptr(P, S, raw, frame, l - 1, spitch);
+    const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
+    const uint32_t ty = tab[g.ytab + dy];
+    const int oy = ty & 0xFFFF;
+    const uint32_t cy1 = ty >> 16, cy0 = 256u - cy1;
+    const uint8_t* r0 = src + (int64_t)oy * spitch;
+    const uint8_t* r1 = src + (int64_t)min(oy + 1, sh - 1) * spitch;
+    uint32_t outw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = gx * 4 + i;
+        if (dx < g.w) {
+            const uint32_t tx = tab[g.xtab + dx];
+            const int ox = tx & 0xFFFF, ox1 = min(ox + 1, sw - 1);
+            const uint32_t cx1 = tx >> 16, cx0 = 256u - cx1;
+            const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
+            const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+            const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
+            outw |= min(v, 255u) << (8 * i);
+        }
+    }
+    uint8_t* dst = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
+    *reinterpret_cast<uint32_t*>(dst + (int64_t)dy * g.pitch + gx * 4) = outw;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a6.2 + a6.7  one 64x32 tile of one level of one frame per workgroup.
+// ------------------------------------------------------------------------------------------------------
+// ring of radius 3 in circular order (fast_score.cpp makeOffsets); only circular adjacency matters
+#define RING_DX {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
+#define RING_DY {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
+
+// FAST-9/16 test + cornerScore<16> at LDS patch position c (row pitch kPatchW). Returns 0 if not a corner,
+// else the score (>= threshold). fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>.
+__device__ __forceinline__ int fast9_score(const uint8_t* c, int t) {
+    constexpr int dxs[16] = RING_DX;
+    constexpr int dys[16] = RING_DY;
+    const int v = c[0];
+    const int lo = v - t, hi = v + t;
+    // any 9 consecutive ring positions contain at least two of the compass points 0,4,8,12
+    int p0 = c[dys[0] * kPatchW + dxs[0]], p4 = c[dys[4] * kPatchW + dxs[4]];
+    int p8 = c[dys[8] * kPatchW + dxs[8]], p12 = c[dys[12] * kPatchW + dxs[12]];
+    int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
+    int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
+    if (nd < 2 && nb < 2) return 0;
+    int d[16];
+    uint32_t dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int p = c[dys[k] * kPatchW + dxs[k]];
+        d[k] = v - p;
+        dark |= (uint32_t)(p < lo) << k;
+        bright |= (uint32_t)(p > hi) << k;
+    }
+    uint32_t m = dark | (dark << 16);
+    uint32_t a = m & (m >> 1);
+    a &= a >> 2;
+    a &= a >> 4;
+    a &= m >> 8;
+    uint32_t mb = bright | (bright << 16);
+    uint32_t b = mb & (mb >> 1);
+    b &= b >> 2;
+    b &= b >> 4;
+    b &= mb >> 8;
+    if (((a | b) & 0xFFFFu) == 0) return 0;
+    // score = max over the 16 nine-arcs of min(d) and of min(-d), minus 1
+    int mn2[16], mx2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int q0 = -1000, q1 = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        q0 = max(q0, mn9);
+        q1 = min(q1, mx9);
+    }
+    return max(q0, -q1) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_blur(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                   uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
+                                                   int* __restrict__ cand_cnt, int* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_pix[kPatchH * kPatchW];
+    __shared__ uint8_t s_score[(kTileH + 2) * (kTileW + 4)];
+    __shared__ uint16_t s_row[(kTileH + 6) * kTileW];
+
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.y;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kLevels; i++)
+        if ((int)blockIdx.x >= P.lv[i].tile_base) l = i;
+    const LevelGeom g = P.lv[l];
+    const int t_in = blockIdx.x - g.tile_base;
+    const int tyi = t_in / g.tiles_x, txi = t_in - tyi * g.tiles_x;
+    const int x0 = txi * kTileW, y0 = tyi * kTileH;
+    int pitch;
+    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
+    const bool can_dword = (l > 0) || S.aligned4;
+
+    // ---- stage the (64+8) x (32+8) patch in LDS, BORDER_REFLECT_101 outside the level ----
+    for (int i = tid; i < kPatchH * (kPatchW / 4); i += 256) {
+        const int r = i / (kPatchW / 4), dcol = i - r * (kPatchW / 4);
+        const int gy = reflect101(y0 - kHalo + r, g.h);
+        const int gx = x0 - kHalo + dcol * 4;
+        const uint8_t* rowp = img + (int64_t)gy * pitch;
+        uint32_t w;
+        if (can_dword && gx >= 0 && gx + 3 < g.w) {
+            w = *reinterpret_cast<const uint32_t*>(rowp + gx);
+        } else {
+            w = (uint32_t)rowp[reflect101(gx, g.w)] | ((uint32_t)rowp[reflect101(gx + 1, g.w)] << 8) |
+                ((uint32_t)rowp[reflect101(gx + 2, g.w)] << 16) | ((uint32_t)rowp[reflect101(gx + 3, g.w)] << 24);
+        }
+        *reinterpret_cast<uint32_t*>(&s_pix[r * kPatchW + dcol * 4]) = w;
+    }
+    __syncthreads();
+
+    // ---- FAST score on the tile + 1 ring; only where a kept corner or its NMS neighbour can be ----
+    // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); clears all if the level is <= 62
+    const bool level_has_kp = (g.w > 2 * kEdgeThreshold) && (g.h > 2 * kEdgeThreshold);
+    const int t = P.fast_threshold;
+    constexpr int SW = kTileW + 4;  // score row pitch
+    for (int i = tid; i < (kTileH + 2) * (kTileW + 2); i += 256) {
+        const int sy = i / (kTileW + 2), sx = i - sy * (kTileW + 2);
+        const int X = x0 - 1 + sx, Y = y0 - 1 + sy;
+        int sc = 0;
+        if (level_has_kp && X >= kEdgeThreshold - 1 && X <= g.w - kEdgeThreshold && Y >= kEdgeThreshold - 1 &&
+            Y <= g.h - kEdgeThreshold)
+            sc = fast9_score(&s_pix[(sy + kHalo - 1) * kPatchW + (sx + kHalo - 1)], t);
+        s_score[sy * SW + sx] = (uint8_t)sc;
+    }
+    __syncthreads();
+
+    // ---- 3x3 strict-max NMS + border filter + wave-aggregated append (ballot / popcount prefix) ----
+    uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
+    int* ccnt = cand_cnt + frame * kLevels + l;
+    const int lane = tid & 63;
+    for (int i = tid; i < kTileH * kTileW; i += 256) {
+        const int py = i >> 6, px = i & 63;
+        const int X = x0 + px, Y = y0 + py;
+        bool keep = false;
+        int sc = 0;
+        if (level_has_kp && X >= kEdgeThreshold && X < g.w - kEdgeThreshold && Y >= kEdgeThreshold &&
+            Y < g.h - kEdgeThreshold) {
+            const uint8_t* s = &s_score[(py + 1) * SW + (px + 1)];
+            sc = s[0];
+            keep = sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-SW - 1] && sc > s[-SW] && sc > s[-SW + 1] &&
+                   sc > s[SW - 1] && sc > s[SW] && sc > s[SW + 1];
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(ccnt, __popcll(mask));
+            base = __shfl(base, leader);
+            const int off = __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) {
+                if (base + off < g.cand_cap)
+                    clist[base + off] = (uint32_t)X | ((uint32_t)Y << 11) | ((uint32_t)sc << 22);
+                else
+                    atomicOr(err, ERRBIT_CAND_OVERFLOW);
+            }
+        }
+    }
+
+    // ---- 7x7 Gaussian, integer kernel {18,34,49,55,49,34,18} per pass (sum 257, not renormalised) ----
+    // row pass: rows y0-3 .. y0+34 of the level = patch rows 1..38
+    for (int i = tid; i < (kTileH + 6) * kTileW; i += 256) {
+        const int r = i >> 6, cx = i & 63;
+        const uint8_t* p = &s_pix[(r + 1) * kPatchW + cx + kHalo];
+        const int s = 18 * (p[-3] + p[3]) + 34 * (p[-2] + p[2]) + 49 * (p[-1] + p[1]) + 55 * p[0];
+        s_row[r * kTileW + cx] = (uint16_t)s;   // <= 255*257 = 65535
+    }
+    __syncthreads();
+    uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
+    const int body = g.w & ~3;   // SymmColumnVec_32s8u covers x < (w & ~3) with ties-to-even
+    for (int i = tid; i < kTileH * (kTileW / 4); i += 256) {
+        const int py = i >> 4, qx = (i & 15) * 4;
+        const int X = x0 + qx, Y = y0 + py;
+        if (Y >= g.h || X >= g.w) continue;
+        uint32_t outw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint16_t* c = &s_row[py * kTileW + qx + j];
+            const int s = 18 * (c[0] + c[6 * kTileW]) + 34 * (c[kTileW] + c[5 * kTileW]) +
+                          49 * (c[2 * kTileW] + c[4 * kTileW]) + 55 * c[3 * kTileW];
+            int q = s >> 16;
+            const int rem = s & 0xFFFF;
+            if (rem > 32768) q += 1;
+            else if (rem == 32768) q += (P.tie_mode == 1 && (X + j) < body) ? (q & 1) : 1;
+            outw |= (uint32_t)min(q, 255) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(bl + (int64_t)Y * g.pitch + X) = outw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a6.3-a6.5  one workgroup per (frame, level)
+// ------------------------------------------------------------------------------------------------------
+// orb.cpp HarrisResponses(blockSize 7, k 0.04f)
+__device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, int x, int y) {
+    int a = 0, b = 0, c = 0;
+    const uint8_t* base = img + (int64_t)(y - 4) * pitch + (x - 4);
+    int prev[9], cur[9], nxt[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { prev[j] = base[j]; cur[j] = base[pitch + j]; }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const uint8_t* rp = base + (int64_t)(i + 2) * pitch;
+#pragma unroll
+        for (int j = 0; j < 9; j++) nxt[j] = rp[j];
+#pragma unroll
+        for (int j = 1; j <= 7; j++) {
+            const int Ix = (cur[j + 1] - cur[j - 1]) * 2 + (prev[j + 1] - prev[j - 1]) + (nxt[j + 1] - nxt[j - 1]);
+            const int Iy = (nxt[j] - prev[j]) * 2 + (nxt[j - 1] - prev[j - 1]) + (nxt[j + 1] - prev[j + 1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            c += Ix * Iy;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) { prev[j] = cur[j]; cur[j] = nxt[j]; }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    const float k = 0.04f;
+    return ((float)a * (float)b - (float)c * (float)c - k * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
+}
+
+__global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                                uint2* __restrict__ sel, int* __restrict__ sel_cnt,
+                                                int* __restrict__ err) {
+    __shared__ unsigned long long s_keys[kSortCap];
+    __shared__ int s_hist[256];
+    __shared__ int s_misc[4];   // [0] threshold score, [1] n1, [2] n2
+
+    const int tid = threadIdx.x;
+    const int l = blockIdx.x, frame = blockIdx.y;
+    const LevelGeom g = P.lv[l];
+    const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
+    const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
+    const int q = g.quota;
+
+    if (q == 0 || n == 0) {   // retainBest(keypoints, 0) clears
+        if (tid == 0) sel_cnt[frame * kLevels + l] = 0;
+        return;
+    }
+    s_hist[tid] = 0;
+    if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[clist[i] >> 22], 1);
+    __syncthreads();
+    // keypoint.cpp retainBest(2*quota) on the FAST score: keep every score >= the (2q)-th largest
+    if (tid == 0) {
+        int thr = 0;
+        if (n > 2 * q) {
+            int cum = 0;
+            for (int s = 255; s >= 0; s--) {
+                cum += s_hist[s];
+                if (cum >= 2 * q) { thr = s; break; }
+            }
+        }
+        s_misc[0] = thr;
+    }
+    __syncthreads();
+    const int thr = s_misc[0];
+    int pitch;
+    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t cd = clist[i];
+        if ((int)(cd >> 22) >= thr) {
+            const int x = cd & 0x7FF, y = (cd >> 11) & 0x7FF;
+            const int slot = atomicAdd(&s_misc[1], 1);
+            if (slot < kSortCap) {
+                const float r = harris_response(img, pitch, x, y);
+                uint32_t u = __float_as_uint(r);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order integer image of the float
+                s_keys[slot] = ((unsigned long long)(~u) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
+            }
+        }
+    }
+    __syncthreads();
+    int n1 = s_misc[1];
+    if (n1 > kSortCap) {
+        if (tid == 0) atomicOr(err, ERRBIT_SORT_OVERFLOW);
+        n1 = kSortCap;
+    }
+    int np = 1;
+    while (np < n1) np <<= 1;
+    for (int i = n1 + tid; i < np; i += 256) s_keys[i] = ~0ull;
+    __syncthreads();
+    // bitonic sort, ascending on (~harris_order, y, x) == Harris descending, then y, then x
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np >> 1); t += 256) {
+                const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int i1 = i0 | j;
+                const unsigned long long a = s_keys[i0], b = s_keys[i1];
+                const bool up = (i0 & k) == 0;
+                if ((a > b) == up) { s_keys[i0] = b; s_keys[i1] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // retainBest(quota) on Harris: first q plus everything tying with the q-th
+    int n2 = n1;
+    if (n1 > q) {
+        const uint32_t cut = (uint32_t)(s_keys[q - 1] >> 32);
+        for (int i = q + tid; i < n1; i += 256)
+            if ((uint32_t)(s_keys[i] >> 32) == cut) atomicAdd(&s_misc[2], 1);
+        __syncthreads();
+        n2 = q + s_misc[2];
+    }
+    if (n2 > g.sel_cap) {
+        if (tid == 0) atomicOr(err, ERRBIT_SEL_OVERFLOW);
+        n2 = g.sel_cap;
+    }
+    uint2* out = sel + (int64_t)frame * P.sel_frame_entries + g.sel_off;
+    for (int i = tid; i < n2; i += 256) {
+        const unsigned long long kk = s_keys[i];
+        uint32_t u = ~(uint32_t)(kk >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        out[i] = make_uint2((uint32_t)kk, u);   // (x | y << 16, harris bits)
+    }
+    if (tid == 0) sel_cnt[frame * kLevels + l] = n2;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a6.6 + a6.8  one wave per selected keypoint
+// ------------------------------------------------------------------------------------------------------
+// mathfuncs_core.dispatch.cpp fastAtan2 (scalar atan_f32)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// Double-precision sin/cos from IEEE add/mul/floor only (Cody-Waite by pi/2 + fdlibm kernel polynomials):
+// the same operation sequence on x86 and gfx950 gives the same bits. Stands in for orb.cpp's
+// (float)cos(angle) / (float)sin(angle), whose libm call is platform-defined in its last double ulp.
+__device__ __forceinline__ void det_sincos(double x, double& s, double& c) {
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double fn = floor(x * invpio2 + 0.5);
+    const double r = (x - fn * pio2_hi) - fn * pio2_lo;
+    const double z = r * r;
+    const double sp = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double sn = r + (z * r) * (S1 + z * sp);
+    const double cp = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double cs = 1.0 - (0.5 * z - z * cp);
+    const int qd = (int)fn & 3;
+    s = (qd == 0) ? sn : (qd == 1) ? cs : (qd == 2) ? -sn : -cs;
+    c = (qd == 0) ? cs : (qd == 1) ? -sn : (qd == 2) ? -cs : sn;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                  const uint8_t* __restrict__ blur, const uint2* __restrict__ sel,
+                                                  const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
+                                                  int* __restrict__ err) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int* cnt = sel_cnt + frame * kLevels;
+    int l = 0, base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kLevels; i++) {
+        const int ci = cnt[i];
+        if (i > 0 && slot >= P.lv[i].sel_off) { l = i; base = total; }
+        total += ci;
+    }
+    if (slot == 0 && lane == 0) counts[frame] = min(total, kp_cap);
+    if (slot >= P.sel_frame_entries) return;
+    const LevelGeom g = P.lv[l];
+    const int i = slot - g.sel_off;
+    if (i >= cnt[l]) return;
+    const int oidx = base + i;
+    if (oidx >= kp_cap) {
+        if (lane == 0) atomicOr(err, ERRBIT_KPCAP);
+        return;
+    }
+    const uint2 sv = sel[(int64_t)frame * P.sel_frame_entries + slot];
+    const int x = sv.x & 0xFFFF, y = sv.x >> 16;
+
+    // ---- orb.cpp ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (integer, order-free) ----
+    int pitch;
+    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
+    const uint8_t* ctr = img + (int64_t)y * pitch + x;
+    constexpr int umax[16] = ARIA_UMAX_LIST;
+    const int u = (lane & 31) - kHalfPatch;
+    const bool lane_ok = (lane & 31) < 31;
+    const int sgn = (lane >> 5) ? -1 : 1;   // lanes 0..30: row +v, lanes 32..62: row -v
+    int m10 = 0, m01 = 0;
+    if (lane_ok && sgn == 1) m10 = u * (int)ctr[u];
+#pragma unroll
+    for (int v = 1; v <= kHalfPatch; v++) {
+        if (lane_ok && abs(u) <= umax[v]) {
+            const int val = ctr[(int64_t)(sgn * v) * pitch + u];
+            m10 += u * val;
+            m01 += sgn * v * val;
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- orb.cpp computeOrbDescriptors (WTA_K 2) on the blurred level ----
+    float ang = angle;
+    ang *= (float)(3.1415926535897932384626433832795 / 180.f);
+    double sd, cd;
+    det_sincos((double)ang, sd, cd);
+    const float a = (float)cd, b = (float)sd;
+    const uint8_t* bc = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off + (int64_t)y * g.pitch + x;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const signed char* pt = &kPattern31[(w * 64 + lane) * 4];
+        const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+        const float fx0 = px0 * a - py0 * b, fy0 = px0 * b + py0 * a;
+        const float fx1 = px1 * a - py1 * b, fy1 = px1 * b + py1 * a;
+        const int t0 = bc[(int)rintf(fy0) * g.pitch + (int)rintf(fx0)];
+        const int t1 = bc[(int)rintf(fy1) * g.pitch + (int)rintf(fx1)];
+        const unsigned long long m = __ballot(t0 < t1);
+        if (lane == w) mine = m;
+    }
+    const int64_t orow = (int64_t)frame * kp_cap + oidx;
+    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + orow * 32)[lane] = mine;
+    if (lane == 0) {
+        aria_keypoint k;
+        k.x = (float)x * g.scale;          // orb.cpp computeKeyPoints: pt *= layerScale[octave]
+        k.y = (float)y * g.scale;
+        k.size = kPatchSize * g.scale;     // size = patchSize * sf
+        k.angle = angle;
+        k.response = __uint_as_float(sv.y);
+        k.octave = l;
+        kps[orow] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
+                          aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st) {
+    hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
+    for (int l = 1; l < kLevels; l++) {
+        const int items = (P.lv[l].pitch >> 2) * P.lv[l].h;
+        dim3 grid((items + 255) / 256, n_frames);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, P, S, D.raw, D.tab, l);
+    }
+    hipLaunchKernelGGL(k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur, D.cand,
+                       D.cand_cnt, D.err);
+    hipLaunchKernelGGL(k_select, dim3(kLevels, n_frames), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel,
+                       D.sel_cnt, D.err);
+    hipLaunchKernelGGL(k_describe, dim3((P.sel_frame_entries + 3) / 4, n_frames), dim3(256), 0, st, P, S, D.raw,
+                       D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err);
+}
+
+}  // namespace aria

@@ -1,0 +1,63 @@
+// Per-(width,height,nfeatures) execution plan shared by host code and kernels (passed by value as a kernel
+// argument). Geometry follows CPU cv::ORB (OpenCV 4.9.0 orb.cpp detectAndCompute / computeKeyPoints) with the
+// parameters the reference fixes at src/adapters/gpu/OrbCudaExtractor.cpp:35-45.
+#pragma once
+#include <cstdint>
+
+namespace aria {
+
+constexpr int kLevels = 8;            // OrbCudaExtractor.cpp:38
+constexpr float kScaleFactor = 1.2f;  // :37
+constexpr int kEdgeThreshold = 31;    // :39
+constexpr int kPatchSize = 31;        // :43
+constexpr int kFastThreshold = 20;    // :44
+constexpr int kHalfPatch = 15;
+
+// FAST + blur tile (one 256-thread workgroup): 64 x 32 output pixels, 4-px halo.
+constexpr int kTileW = 64;
+constexpr int kTileH = 32;
+constexpr int kHalo = 4;
+constexpr int kPatchW = kTileW + 2 * kHalo;  // 72
+constexpr int kPatchH = kTileH + 2 * kHalo;  // 40
+
+constexpr int kSortCap = 4096;   // LDS bitonic sort capacity of the per-(frame,level) selection kernel
+constexpr int kSelSlack = 64;    // extra output slots per level for ties at the Harris cut
+constexpr int kMaxDim = 2047;    // candidate packing: x:11 | y:11 | score:8
+
+struct LevelGeom {
+    int w, h;          // level size in pixels
+    int pitch;         // row pitch of this level in the raw / blurred scratch (multiple of 16)
+    int quota;         // nfeaturesPerLevel
+    int cand_cap;      // FAST candidate list capacity (entries)
+    int cand_off;      // entry offset of the level's list inside a frame's candidate block
+    int sel_cap;       // selected-keypoint capacity (quota + kSelSlack)
+    int sel_off;       // entry offset inside a frame's selection block
+    int tiles_x;       // FAST/blur tiles per row
+    int tile_base;     // first tile id of this level in the all-level tile enumeration
+    int xtab, ytab;    // offsets (in uint32) of the resize coefficient tables (level >= 1)
+    float scale;       // layerScale
+    int _pad;
+    int64_t raw_off;   // byte offset of the level inside a frame's raw-pyramid block (level 0: caller image)
+    int64_t blur_off;  // byte offset inside a frame's blurred-pyramid block
+};
+
+struct Plan {
+    LevelGeom lv[kLevels];
+    int width, height;
+    int nfeatures;
+    int total_tiles;
+    int cand_frame_entries;   // candidate entries per frame (all levels)
+    int sel_frame_entries;    // selection entries per frame (all levels)
+    int tie_mode;
+    int fast_threshold;
+    int64_t raw_frame_bytes;
+    int64_t blur_frame_bytes;
+    int64_t pixels_total;     // P of BASELINE.md section 3
+};
+
+// Host-side construction (orb_plan.cpp). tab receives the packed resize coefficients (ofs | c1 << 16).
+int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie_mode, Plan* plan,
+               uint32_t* tab, int tab_capacity, int* tab_used);
+int64_t plan_tab_entries(int width, int height);
+
+}  // namespace aria

@@ -1,0 +1,229 @@
+"""Python mirror of the reference's extractor / matcher ports, bound to the C-ABI.
+
+Names and argument meaning follow the reference interfaces so that the parity tests read like tests of the
+reference adapters would:
+  IFeatureExtractor  extract / extractAsync / sync / setMaxFeatures / getMaxFeatures
+                     (reference include/interfaces/IFeatureExtractor.hpp:18-39,
+                      src/adapters/gpu/OrbCudaExtractor.cpp:64-216)
+  IMatcher           match / matchMultiple
+                     (reference include/interfaces/IMatcher.hpp:19-37, src/adapters/gpu/CudaMatcher.cpp:28-68)
+A "frame" here is a dict with the fields the extractor fills in aria::core::Frame (include/core/Types.hpp:18-31):
+width, height, keypoints (structured array, KP_DTYPE), descriptors (N x 32 uint8).
+The C++ adapters under aria_slam_amd/host are the drop-in classes; this module only serves tests and bench.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, MATCH_DTYPE, AriaError, check
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor, or an int passed through."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+class OrbHipExtractor:
+    """Replaces aria::adapters::gpu::OrbCudaExtractor (reference include/adapters/gpu/OrbCudaExtractor.hpp)."""
+
+    def __init__(self, max_features=1000, stream=None, device=0, max_width=640, max_height=480, max_batch=1,
+                 blur_tie_mode=1, cand_cap_scale=0):
+        self._L = _lib.load_library()
+        cfg = _lib.OrbConfig()
+        self._L.aria_orb_default_config(C.byref(cfg))
+        cfg.device = device
+        cfg.stream = stream
+        cfg.max_width, cfg.max_height = max_width, max_height
+        cfg.max_features = max_features
+        cfg.max_batch = max_batch
+        cfg.blur_tie_mode = blur_tie_mode
+        cfg.cand_cap_scale = cand_cap_scale
+        h = C.c_void_p()
+        check(self._L.aria_orb_create(C.byref(cfg), C.byref(h)), "aria_orb_create")
+        self._h = h
+        self._pending = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.aria_orb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- IFeatureExtractor ----
+    def extract(self, image_data, width=None, height=None, frame=None):
+        img = np.ascontiguousarray(image_data, np.uint8)
+        if width is None:
+            height, width = img.shape
+        cap = self.kp_capacity()
+        kps = np.empty(cap, KP_DTYPE)
+        desc = np.empty((cap, 32), np.uint8)
+        n = C.c_int()
+        check(self._L.aria_orb_extract(self._h, img.ctypes.data, width, height, width, kps.ctypes.data,
+                                       desc.ctypes.data, cap, C.byref(n)), "aria_orb_extract")
+        return self._fill(frame, width, height, kps[:n.value].copy(), desc[:n.value].copy())
+
+    def extractAsync(self, image_data, width=None, height=None, frame=None):
+        img = np.ascontiguousarray(image_data, np.uint8)
+        if width is None:
+            height, width = img.shape
+        check(self._L.aria_orb_extract_async(self._h, img.ctypes.data, width, height, width), "aria_orb_extract_async")
+        self._pending = (img, width, height, frame if frame is not None else {})
+        return self._pending[3]
+
+    def sync(self):
+        if self._pending is None:   # OrbCudaExtractor.cpp:177 "if (!pending_frame_) return;"
+            return None
+        img, width, height, frame = self._pending
+        self._pending = None
+        cap = self.kp_capacity()
+        kps = np.empty(cap, KP_DTYPE)
+        desc = np.empty((cap, 32), np.uint8)
+        n = C.c_int()
+        check(self._L.aria_orb_sync(self._h, kps.ctypes.data, desc.ctypes.data, cap, C.byref(n)), "aria_orb_sync")
+        return self._fill(frame, width, height, kps[:n.value].copy(), desc[:n.value].copy())
+
+    def setMaxFeatures(self, n):
+        check(self._L.aria_orb_set_max_features(self._h, int(n)), "aria_orb_set_max_features")
+
+    def getMaxFeatures(self):
+        return self._L.aria_orb_get_max_features(self._h)
+
+    # ---- device-resident batch form (OrbCudaExtractor::getGpuDescriptors' role) ----
+    def kp_capacity(self):
+        return self._L.aria_orb_kp_capacity(self._h)
+
+    def extract_batch_device(self, d_images, n_frames, width, height, d_keypoints, d_descriptors, d_counts, kp_cap,
+                             frame_stride=None, row_stride=None):
+        row_stride = width if row_stride is None else row_stride
+        frame_stride = row_stride * height if frame_stride is None else frame_stride
+        check(self._L.aria_orb_extract_batch_device(self._h, _ptr(d_images), n_frames, width, height, frame_stride,
+                                                    row_stride, _ptr(d_keypoints), _ptr(d_descriptors),
+                                                    _ptr(d_counts), kp_cap), "aria_orb_extract_batch_device")
+
+    def check(self):
+        check(self._L.aria_orb_check(self._h), "aria_orb_check")
+
+    @property
+    def stream(self):
+        return self._L.aria_orb_stream(self._h)
+
+    # ---- introspection for parity tests ----
+    def level_info(self, width, height):
+        out = []
+        for l in range(8):
+            lw, lh, q, s = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+            check(self._L.aria_orb_level_info(self._h, width, height, l, C.byref(lw), C.byref(lh), C.byref(q),
+                                              C.byref(s)), "aria_orb_level_info")
+            out.append((lw.value, lh.value, q.value, s.value))
+        return out
+
+    def debug_read_level(self, level, blurred, lw, lh):
+        out = np.empty((lh, lw), np.uint8)
+        check(self._L.aria_orb_debug_read_level(self._h, level, int(bool(blurred)), out.ctypes.data),
+              "aria_orb_debug_read_level")
+        return out
+
+    def algorithmic_bytes(self, width, height, n_keypoints):
+        be, bf = C.c_int64(), C.c_int64()
+        check(self._L.aria_orb_algorithmic_bytes(self._h, width, height, n_keypoints, C.byref(be), C.byref(bf)),
+              "aria_orb_algorithmic_bytes")
+        return be.value, bf.value
+
+    @staticmethod
+    def _fill(frame, width, height, kps, desc):
+        frame = {} if frame is None else frame
+        frame["width"], frame["height"] = width, height       # OrbCudaExtractor.cpp:109-110
+        frame["keypoints"] = kps                               # :111-123 (cleared, then refilled)
+        frame["descriptors"] = desc                            # :126-127
+        return frame
+
+
+class HipMatcher:
+    """Replaces aria::adapters::gpu::CudaMatcher (reference include/adapters/gpu/CudaMatcher.hpp)."""
+
+    def __init__(self, stream=None, device=0, max_query=4096, max_train=4096):
+        self._L = _lib.load_library()
+        cfg = _lib.MatcherConfig()
+        self._L.aria_matcher_default_config(C.byref(cfg))
+        cfg.device, cfg.stream, cfg.max_query, cfg.max_train = device, stream, max_query, max_train
+        h = C.c_void_p()
+        check(self._L.aria_matcher_create(C.byref(cfg), C.byref(h)), "aria_matcher_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.aria_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _desc(frame_or_array):
+        d = frame_or_array["descriptors"] if isinstance(frame_or_array, dict) else frame_or_array
+        return np.ascontiguousarray(d, np.uint8).reshape(-1, 32)
+
+    # ---- IMatcher ----
+    def match(self, query, train, matches=None, ratio_threshold=0.75):
+        """Appends to `matches` (a list) like CudaMatcher::match appends to the vector (CudaMatcher.cpp:65)."""
+        q, t = self._desc(query), self._desc(train)
+        out = np.empty(max(len(q), 1), MATCH_DTYPE)
+        n = C.c_int()
+        check(self._L.aria_matcher_match(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t),
+                                         C.c_float(ratio_threshold), out.ctypes.data, len(out), C.byref(n)),
+              "aria_matcher_match")
+        res = out[:n.value].copy()
+        if matches is not None:
+            matches.extend(res.tolist())
+        return res
+
+    def matchMultiple(self, query, candidates, all_matches=None, ratio_threshold=0.75):
+        """IMatcher.hpp:27-37: resize the outer list, then match against every candidate."""
+        out = [self.match(query, c, None, ratio_threshold) for c in candidates]
+        if all_matches is not None:
+            del all_matches[len(candidates):]
+            while len(all_matches) < len(candidates):
+                all_matches.append([])
+            for dst, src in zip(all_matches, out):
+                dst.extend(src.tolist())
+        return out
+
+    def knn2(self, query, train):
+        q, t = self._desc(query), self._desc(train)
+        idx = np.empty((len(q), 2), np.int32)
+        dist = np.empty((len(q), 2), np.int32)
+        check(self._L.aria_matcher_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data if len(t) else None, len(t),
+                                        idx.ctypes.data, dist.ctypes.data), "aria_matcher_knn2")
+        return idx, dist
+
+    # ---- device-resident forms (CudaMatcher::matchGpu's role) ----
+    def match_batch_device(self, d_query, d_nq, d_train, d_nt, n_pairs, desc_stride, ratio, d_matches, d_nmatches,
+                           match_cap):
+        check(self._L.aria_matcher_match_batch_device(self._h, _ptr(d_query), _ptr(d_nq), _ptr(d_train), _ptr(d_nt),
+                                                      n_pairs, desc_stride, C.c_float(ratio), _ptr(d_matches),
+                                                      _ptr(d_nmatches), match_cap), "aria_matcher_match_batch_device")
+
+    def match_db_device(self, d_query, nq, d_db, d_kf_counts, n_kf, desc_stride, ratio, d_good):
+        check(self._L.aria_matcher_match_db_device(self._h, _ptr(d_query), nq, _ptr(d_db), _ptr(d_kf_counts), n_kf,
+                                                   desc_stride, C.c_double(ratio), _ptr(d_good)),
+              "aria_matcher_match_db_device")
+
+    def sync(self):
+        check(self._L.aria_matcher_sync(self._h), "aria_matcher_sync")
+
+    @property
+    def stream(self):
+        return self._L.aria_matcher_stream(self._h)

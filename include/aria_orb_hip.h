@@ -1,0 +1,175 @@
+/*
+ * aria_orb_hip.h -- C-ABI of the MI355X-native ORB extractor + brute-force Hamming matcher.
+ *
+ * This is the drop-in boundary for aria-slam's feature front-end. Each entry point names
+ * the reference interface it replaces; paths are relative to the reference tree (robertteleng/aria-slam).
+ * Plain pointers and sizes only: no C++ types, no torch types, never throws. All functions return an
+ * aria_status (0 = OK, negative = error); aria_status_string() explains a code.
+ *
+ * Conventions
+ *  - Images are 8-bit grayscale, row-major (include/interfaces/IFeatureExtractor.hpp:14).
+ *  - aria_keypoint / aria_match are byte-for-byte aria::core::KeyPoint / aria::core::Match
+ *    (include/core/Types.hpp:9-15, :97-101); descriptors are N x 32 bytes, row-major (Types.hpp:25,29).
+ *  - The ORB configuration is the one the reference hard-codes (src/adapters/gpu/OrbCudaExtractor.cpp:35-45):
+ *    scaleFactor 1.2f, 8 levels, edgeThreshold 31, firstLevel 0, WTA_K 2, HARRIS_SCORE, patchSize 31,
+ *    fastThreshold 20; only nfeatures is settable, as in the reference (setMaxFeatures, :212-216).
+ *  - Results follow CPU cv::ORB::detectAndCompute (src/legacy/Frame.cpp:45-49), not cv::cuda::ORB.
+ *    Keypoint order is canonical: level ascending; within a level response (Harris) descending, then y, then
+ *    x ascending. A level may return more than its quota when responses tie at the cut (OpenCV keeps ties),
+ *    so a frame can yield slightly more than max_features keypoints; size outputs with aria_orb_kp_capacity().
+ *  - A handle is single-owner (not thread-safe), like the reference adapters
+ *    (include/adapters/gpu/OrbCudaExtractor.hpp:38-50). Independent handles on different devices/streams
+ *    may run concurrently. The library never returns memory it owns; callers allocate every output.
+ *  - "device" pointers are HIP device pointers on the handle's device; "stream" is a hipStream_t passed as
+ *    void* (borrowed; NULL = the handle creates and owns one: OrbCudaExtractor.cpp:24-29,48-52).
+ */
+#ifndef ARIA_ORB_HIP_H
+#define ARIA_ORB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARIA_ORB_HIP_ABI_VERSION 1
+
+typedef enum {
+    ARIA_OK = 0,
+    ARIA_E_INVALID = -1,          /* bad argument (null pointer, size out of range, bad struct_size)        */
+    ARIA_E_NO_DEVICE = -2,        /* no usable HIP device / HIP runtime error (see aria_last_hip_error)     */
+    ARIA_E_OOM = -3,              /* device or host allocation failed                                       */
+    ARIA_E_TOO_LARGE = -4,        /* image larger than the handle was created for                           */
+    ARIA_E_OUTPUT_TOO_SMALL = -5, /* caller's keypoint/match capacity is smaller than the result            */
+    ARIA_E_OVERFLOW = -6,         /* an internal candidate/sort buffer overflowed (pathological image);
+                                     results are NOT valid. Raise cand_cap_scale and retry.                 */
+    ARIA_E_BUSY = -7,             /* extract_async called while another async extract is pending            */
+    ARIA_E_NOT_PENDING = -8       /* sync called with nothing pending (treated as a no-op by the adapter)   */
+} aria_status;
+
+/* == aria::core::KeyPoint (include/core/Types.hpp:9-15), 24 bytes */
+typedef struct { float x, y, size, angle, response; int octave; } aria_keypoint;
+/* == aria::core::Match (include/core/Types.hpp:97-101), 12 bytes */
+typedef struct { int query_idx, train_idx; float distance; } aria_match;
+
+typedef struct aria_orb_s* aria_orb_t;
+typedef struct aria_matcher_s* aria_matcher_t;
+
+/* Replaces the constructor arguments of OrbCudaExtractor (OrbCudaExtractor.cpp:21-46) and
+ * FactoryConfig{cuda_device, max_features} (include/factory/PipelineFactory.hpp:16-28). */
+typedef struct {
+    int   struct_size;     /* = sizeof(aria_orb_config)                                                     */
+    int   device;          /* HIP device ordinal                                                            */
+    void* stream;          /* borrowed hipStream_t, or NULL                                                 */
+    int   max_width;       /* largest image the handle must accept                                          */
+    int   max_height;
+    int   max_features;    /* nfeatures (OrbCudaExtractor.hpp:12 default 1000)                              */
+    int   max_batch;       /* frames processed per internal pass of the batch entry point (>= 1)            */
+    int   blur_tie_mode;   /* 1 (default): OpenCV SIMD column-filter rounding; 0: ties-up everywhere        */
+    int   cand_cap_scale;  /* per-level candidate buffer = cand_cap_scale * quota entries (0 = default 32)  */
+} aria_orb_config;
+
+const char* aria_status_string(int status);
+int         aria_abi_version(void);
+/* Last HIP runtime error text seen by this thread's most recent failing call ("" if none). */
+const char* aria_last_hip_error(void);
+
+void aria_orb_default_config(aria_orb_config* cfg);
+int  aria_orb_create(const aria_orb_config* cfg, aria_orb_t* out);
+void aria_orb_destroy(aria_orb_t h);
+
+/* IFeatureExtractor::setMaxFeatures / getMaxFeatures (include/interfaces/IFeatureExtractor.hpp:38-39,
+ * OrbCudaExtractor.cpp:212-216). All other ORB parameters keep the reference's values. */
+int aria_orb_set_max_features(aria_orb_t h, int n);
+int aria_orb_get_max_features(aria_orb_t h);
+/* Rows to allocate per frame for keypoints/descriptors so that tie overshoot still fits. */
+int aria_orb_kp_capacity(aria_orb_t h);
+
+/* IFeatureExtractor::extract (IFeatureExtractor.hpp:18-23; OrbCudaExtractor.cpp:64-128). Host buffers.
+ * image is borrowed and never written; stride = bytes between rows (width for the reference's packed Mat,
+ * OrbCudaExtractor.cpp:72). Writes up to cap keypoints (24 B each) and cap*32 descriptor bytes; *n_out = count.
+ * Returns ARIA_E_OUTPUT_TOO_SMALL (with *n_out = required) if cap is too small. Blocks until done. */
+int aria_orb_extract(aria_orb_t h, const uint8_t* image, int width, int height, int stride,
+                     aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out);
+
+/* IFeatureExtractor::extractAsync + sync (IFeatureExtractor.hpp:27-35; OrbCudaExtractor.cpp:136-210).
+ * One pending operation per handle, as in the reference. The image buffer must stay valid until
+ * aria_orb_sync returns (the upload is asynchronous, :158). */
+int aria_orb_extract_async(aria_orb_t h, const uint8_t* image, int width, int height, int stride);
+int aria_orb_sync(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out);
+
+/* Device-resident batch form: the role OrbCudaExtractor::getGpuDescriptors() was meant to play
+ * (include/adapters/gpu/OrbCudaExtractor.hpp:35) -- results stay in HBM for the matcher.
+ *   d_images     : n_frames images, frame f at d_images + f*frame_stride, rows row_stride bytes apart
+ *   d_keypoints  : n_frames * kp_cap records (frame f at index f*kp_cap)
+ *   d_descriptors: n_frames * kp_cap * 32 bytes
+ *   d_counts     : n_frames ints, keypoints found per frame
+ * Enqueued on the handle's stream; returns without synchronising. Call aria_orb_check() after a stream
+ * sync to learn whether any frame overflowed an internal buffer or kp_cap. */
+int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_frames, int width, int height,
+                                  int64_t frame_stride, int row_stride,
+                                  aria_keypoint* d_keypoints, uint8_t* d_descriptors, int* d_counts, int kp_cap);
+/* Synchronises the handle's stream and returns ARIA_OK or the first deferred error (overflow flags). */
+int aria_orb_check(aria_orb_t h);
+void* aria_orb_stream(aria_orb_t h);
+
+/* Introspection for parity tests and benchmarks (no reference counterpart): pyramid geometry, and copies
+ * of frame 0's intermediate buffers of the most recent call. level in [0, 8). */
+int aria_orb_level_info(aria_orb_t h, int width, int height, int level, int* lw, int* lh, int* quota, float* scale);
+int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* host_out /* lw*lh, packed */);
+/* Algorithmic bytes of one frame: b_extract = 5P - p0 - p7 + 56N, b_fused = 2P + 56N. */
+int aria_orb_algorithmic_bytes(aria_orb_t h, int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused);
+
+/* ---- matcher: replaces CudaMatcher (include/adapters/gpu/CudaMatcher.hpp, src/adapters/gpu/CudaMatcher.cpp) -- */
+typedef struct {
+    int   struct_size;
+    int   device;
+    void* stream;      /* borrowed hipStream_t or NULL (CudaMatcher.cpp:9-17,22-26) */
+    int   max_query;   /* rows per descriptor set the host entry points must accept */
+    int   max_train;
+} aria_matcher_config;
+
+void aria_matcher_default_config(aria_matcher_config* cfg);
+int  aria_matcher_create(const aria_matcher_config* cfg, aria_matcher_t* out);
+void aria_matcher_destroy(aria_matcher_t m);
+
+/* IMatcher::match (include/interfaces/IMatcher.hpp:19-24; CudaMatcher.cpp:28-68). Host buffers.
+ * Brute-force Hamming kNN (k = 2) of every query row against every train row (ties: lower train index
+ * first, as CPU cv::BFMatcher), then Lowe's test d0 < ratio*d1 in fp32 (CudaMatcher.cpp:60). Matches are
+ * written in query order. nq == 0 or nt == 0 -> *n_out = 0 (CudaMatcher.cpp:35-37). nt == 1 -> no matches
+ * (knn.size() >= 2 fails, :60). ratio == 0 means "ratio test disabled" as IMatcher.hpp:18 documents:
+ * the best match of every query is returned (the reference adapter would return nothing). */
+int aria_matcher_match(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* train_desc, int nt,
+               float ratio, aria_match* matches, int cap, int* n_out);
+
+/* Raw kNN-2 (cv::BFMatcher::knnMatch(k=2) itself), host buffers: idx/dist hold 2 ints per query
+ * (nearest, second nearest); idx = -1 / dist = INT_MAX where the train set is too small. */
+int aria_matcher_knn2(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* train_desc, int nt,
+                    int* idx, int* dist);
+
+/* Device-resident batch form: the role CudaMatcher::matchGpu was declared for (CudaMatcher.hpp:23-28).
+ * Pair p matches query block (d_query + p*desc_stride bytes, d_nq[p] rows) against train block
+ * (d_train + p*desc_stride, d_nt[p] rows); writes up to match_cap matches at d_matches + p*match_cap and the
+ * count at d_nmatches[p]. Enqueued on the matcher's stream; no synchronisation. */
+int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, const int* d_nq,
+                            const uint8_t* d_train, const int* d_nt, int n_pairs, int64_t desc_stride,
+                            float ratio, aria_match* d_matches, int* d_nmatches, int match_cap);
+
+/* Loop-closure candidate scan, the semantic behind IMatcher::matchMultiple (IMatcher.hpp:27-37) as the
+ * legacy code uses it (src/legacy/LoopClosure.cpp:72-114): one query descriptor set against n_kf keyframe
+ * blocks resident in HBM (block k at d_db + k*desc_stride bytes, d_kf_counts[k] rows). For every keyframe:
+ * kNN-2, ratio test in double (d0 < ratio*d1, LoopClosure.cpp:92), d_good[k] = number of passing queries.
+ * Scoring/top-5 (LoopClosure.cpp:98-111) is host logic in the adapter. */
+int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int nq, const uint8_t* d_db,
+                         const int* d_kf_counts, int n_kf, int64_t desc_stride, double ratio, int* d_good);
+void* aria_matcher_stream(aria_matcher_t m);
+int   aria_matcher_sync(aria_matcher_t m);
+
+/* ---- synthetic workload: integer-only generator, identical bytes everywhere ------------ */
+int aria_synth_frame_pair(uint64_t seed, int width, int height, uint8_t* frame_a, uint8_t* frame_b);
+int aria_synth_sequence(uint64_t seed0, int n_pairs, int width, int height, uint8_t* out, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
