@@ -14,6 +14,7 @@
 #include <climits>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.h"
 
@@ -155,6 +156,32 @@ struct aria_matcher_s {
     aria_match* h_m = nullptr;      // pinned
     int* h_n = nullptr;             // pinned [0] n, [1] err
     int* h_idx = nullptr;           // pinned
+    // optional stage timing (HIP events on the launch stream)
+    bool prof_enabled = false;
+    struct Ev { hipEvent_t e[3]; int pairs; };
+    std::vector<Ev> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[2] = {0, 0};
+    int64_t prof_launches[2] = {0, 0};
+    int64_t prof_pairs = 0;
+    hipEvent_t prof_get() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        hipEventCreate(&e);
+        return e;
+    }
+    void prof_collect() {
+        for (Ev& v : prof_pending) {
+            for (int s = 0; s < 2; s++) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, v.e[s], v.e[s + 1]) == hipSuccess) prof_ms[s] += t;
+                prof_launches[s] += 1;
+            }
+            prof_pairs += v.pairs;
+            for (int s = 0; s < 3; s++) prof_pool.push_back(v.e[s]);
+        }
+        prof_pending.clear();
+    }
 };
 
 namespace {
@@ -248,12 +275,34 @@ void aria_matcher_destroy(aria_matcher_t m) {
     if (!m) return;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
+    m->prof_collect();
+    for (hipEvent_t e : m->prof_pool) hipEventDestroy(e);
     matcher_free(m);
     if (m->owns_stream && m->stream) hipStreamDestroy(m->stream);
     delete m;
 }
 
 void* aria_matcher_stream(aria_matcher_t m) { return m ? (void*)m->stream : nullptr; }
+
+int aria_matcher_set_profiling(aria_matcher_t m, int enable) {
+    if (!m) return ARIA_E_INVALID;
+    m->prof_enabled = enable != 0;
+    return ARIA_OK;
+}
+
+int aria_matcher_get_profile(aria_matcher_t m, int reset, double* stage_ms, int64_t* stage_launches, int64_t* pairs) {
+    if (!m) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(m->device));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    m->prof_collect();
+    for (int s = 0; s < 2; s++) {
+        if (stage_ms) stage_ms[s] = m->prof_ms[s];
+        if (stage_launches) stage_launches[s] = m->prof_launches[s];
+    }
+    if (pairs) *pairs = m->prof_pairs;
+    if (reset) { m->prof_ms[0] = m->prof_ms[1] = 0; m->prof_launches[0] = m->prof_launches[1] = 0; m->prof_pairs = 0; }
+    return ARIA_OK;
+}
 
 int aria_matcher_sync(aria_matcher_t m) {
     if (!m) return ARIA_E_INVALID;
@@ -325,10 +374,15 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
     ARIA_HIP(hipSetDevice(m->device));
     int rc = ensure_keys(m, (size_t)n_pairs * (size_t)maxq);
     if (rc != ARIA_OK) return rc;
+    aria_matcher_s::Ev ev;
+    ev.pairs = n_pairs;
+    if (m->prof_enabled) { for (int s = 0; s < 3; s++) ev.e[s] = m->prof_get(); hipEventRecord(ev.e[0], m->stream); }
     hipLaunchKernelGGL(k_knn2<0>, dim3((unsigned)((maxq + 255) / 256), n_pairs), dim3(256), 0, m->stream, d_query, d_nq,
                        0, d_train, d_nt, 0, desc_stride, desc_stride, m->d_keys, (int)maxq, 0.0, nullptr);
+    if (m->prof_enabled) hipEventRecord(ev.e[1], m->stream);
     hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
                        d_matches, d_nmatches, match_cap, m->d_err);
+    if (m->prof_enabled) { hipEventRecord(ev.e[2], m->stream); m->prof_pending.push_back(ev); }
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

@@ -47,6 +47,7 @@ struct aria_orb_s {
 
     FrameSrc last_src{};
     bool have_last = false;
+    Profiler prof;
 };
 
 namespace {
@@ -125,7 +126,7 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1};
     h->last_src = S;
     h->have_last = true;
-    launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream);
+    launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof);
     ARIA_HIP(hipGetLastError());
     ARIA_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
     ARIA_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, 32 * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
@@ -226,6 +227,7 @@ void aria_orb_destroy(aria_orb_t h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    h->prof.release();
     free_scratch(h);
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -297,7 +299,7 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
         FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4};
         if (f0 == 0) { h->last_src = S; h->have_last = true; }
         launch_extract_chunk(h->plan, S, h->D, nf, d_keypoints + (int64_t)f0 * kp_cap,
-                             d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream);
+                             d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream, &h->prof);
     }
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
@@ -311,6 +313,29 @@ int aria_orb_check(aria_orb_t h) {
     ARIA_HIP(hipMemcpy(&bits, h->D.err, sizeof(int), hipMemcpyDeviceToHost));
     if (bits) ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
     return errbits_to_status(bits);
+}
+
+int aria_orb_set_profiling(aria_orb_t h, int enable) {
+    if (!h) return ARIA_E_INVALID;
+    h->prof.enabled = enable != 0;
+    return ARIA_OK;
+}
+
+int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms, int64_t* stage_launches, int64_t* frames) {
+    if (!h) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(h->device));
+    ARIA_HIP(hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    for (int s = 0; s < STAGE_COUNT; s++) {
+        if (stage_ms) stage_ms[s] = h->prof.ms[s];
+        if (stage_launches) stage_launches[s] = h->prof.launches[s];
+    }
+    if (frames) *frames = h->prof.frames;
+    if (reset) {
+        for (int s = 0; s < STAGE_COUNT; s++) { h->prof.ms[s] = 0; h->prof.launches[s] = 0; }
+        h->prof.frames = 0;
+    }
+    return ARIA_OK;
 }
 
 int aria_orb_level_info(aria_orb_t h, int width, int height, int level, int* lw, int* lh, int* quota, float* scale) {

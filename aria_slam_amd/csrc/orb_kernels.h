@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "aria_orb_hip.h"
 #include "orb_plan.h"
@@ -29,7 +30,26 @@ struct DeviceScratch {
     int* err;            // deferred error bits
 };
 
+// Optional per-stage timing: HIP events recorded on the launch stream around each stage of a chunk.
+enum { STAGE_RESIZE = 0, STAGE_FAST_BLUR = 1, STAGE_SELECT = 2, STAGE_DESCRIBE = 3, STAGE_COUNT = 4 };
+struct StageEvents {
+    hipEvent_t ev[STAGE_COUNT + 1];   // boundaries: ev[s] .. ev[s+1] brackets stage s
+    int n_frames;
+};
+struct Profiler {
+    bool enabled = false;
+    std::vector<StageEvents> pending;     // recorded, not yet read
+    std::vector<hipEvent_t> pool;         // recycled events
+    double ms[STAGE_COUNT] = {0, 0, 0, 0};
+    int64_t launches[STAGE_COUNT] = {0, 0, 0, 0};
+    int64_t frames = 0;
+    hipEvent_t get();
+    void collect();                       // caller has synchronised the stream
+    void release();
+};
+
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
-                          aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st);
+                          aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
+                          Profiler* prof);
 
 }  // namespace aria

@@ -535,20 +535,54 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
+hipEvent_t Profiler::get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+void Profiler::collect() {
+    for (StageEvents& se : pending) {
+        for (int s = 0; s < STAGE_COUNT; s++) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, se.ev[s], se.ev[s + 1]) == hipSuccess) ms[s] += t;
+            launches[s] += (s == STAGE_RESIZE) ? (kLevels - 1) : 1;
+        }
+        frames += se.n_frames;
+        for (int s = 0; s <= STAGE_COUNT; s++) pool.push_back(se.ev[s]);
+    }
+    pending.clear();
+}
+void Profiler::release() {
+    collect();
+    for (hipEvent_t e : pool) hipEventDestroy(e);
+    pool.clear();
+}
+
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
-                          aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st) {
+                          aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
+                          Profiler* prof) {
+    const bool pr = prof && prof->enabled;
+    StageEvents se;
+    se.n_frames = n_frames;
+    if (pr) for (int s = 0; s <= STAGE_COUNT; s++) se.ev[s] = prof->get();
     hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
+    if (pr) hipEventRecord(se.ev[0], st);
     for (int l = 1; l < kLevels; l++) {
         const int items = (P.lv[l].pitch >> 2) * P.lv[l].h;
         dim3 grid((items + 255) / 256, n_frames);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, P, S, D.raw, D.tab, l);
     }
+    if (pr) hipEventRecord(se.ev[1], st);
     hipLaunchKernelGGL(k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur, D.cand,
                        D.cand_cnt, D.err);
+    if (pr) hipEventRecord(se.ev[2], st);
     hipLaunchKernelGGL(k_select, dim3(kLevels, n_frames), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel,
                        D.sel_cnt, D.err);
+    if (pr) hipEventRecord(se.ev[3], st);
     hipLaunchKernelGGL(k_describe, dim3((P.sel_frame_entries + 3) / 4, n_frames), dim3(256), 0, st, P, S, D.raw,
                        D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err);
+    if (pr) { hipEventRecord(se.ev[4], st); prof->pending.push_back(se); }
 }
 
 }  // namespace aria

@@ -113,6 +113,19 @@ class OrbHipExtractor:
     def check(self):
         check(self._L.aria_orb_check(self._h), "aria_orb_check")
 
+    STAGES = ("resize", "fast_blur", "select", "describe")
+
+    def set_profiling(self, enable):
+        check(self._L.aria_orb_set_profiling(self._h, int(bool(enable))), "aria_orb_set_profiling")
+
+    def get_profile(self, reset=True):
+        """{stage: (total_ms, launches)}, frames -- HIP-event times on the launch stream."""
+        ms = (C.c_double * 4)()
+        ln = (C.c_int64 * 4)()
+        fr = C.c_int64()
+        check(self._L.aria_orb_get_profile(self._h, int(reset), ms, ln, C.byref(fr)), "aria_orb_get_profile")
+        return {s: (ms[i], ln[i]) for i, s in enumerate(self.STAGES)}, fr.value
+
     @property
     def stream(self):
         return self._L.aria_orb_stream(self._h)
@@ -223,6 +236,18 @@ class HipMatcher:
 
     def sync(self):
         check(self._L.aria_matcher_sync(self._h), "aria_matcher_sync")
+
+    STAGES = ("knn2", "ratio_compact")
+
+    def set_profiling(self, enable):
+        check(self._L.aria_matcher_set_profiling(self._h, int(bool(enable))), "aria_matcher_set_profiling")
+
+    def get_profile(self, reset=True):
+        ms = (C.c_double * 2)()
+        ln = (C.c_int64 * 2)()
+        pr = C.c_int64()
+        check(self._L.aria_matcher_get_profile(self._h, int(reset), ms, ln, C.byref(pr)), "aria_matcher_get_profile")
+        return {s: (ms[i], ln[i]) for i, s in enumerate(self.STAGES)}, pr.value
 
     @property
     def stream(self):

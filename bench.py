@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of ORB extract + brute-force Hamming match on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a recorded sequence of 4096
+synthetic 640x480 frame pairs = 8192 grayscale frames, 2000 keypoints per frame, resident in HBM before the
+timed region. One "step" = one pass of the hot path over the whole sequence: every frame is extracted (pyramid,
+FAST, Harris, IC angle, rBRIEF) and matched (kNN-2 + ratio 0.75) against the previous frame's descriptors
+(query = current, train = previous; frame 0 matches the last frame of the previous pass). So every frame costs
+1 extract + 1 match. Data: synthetic (SURVEY.md 8d generator, seeds 1..4096 per GPU shard).
+
+Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks clock);
+the sequence shards by contiguous frame ranges, each rank owns 4096 pairs, no data-path collective -> weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(width, height, nfeatures, budget_s=12.0):
+    """Time the CPU oracle (a port of the reference's CPU OpenCV path, oracle/orb_oracle.cpp) on this host:
+    frame-parallel, one worker thread per core, each unit = 1 extract + 1 match (same accounting as the GPU)."""
+    import threading
+    import aria_slam_amd as A
+    from oracle import oracle_py as O
+    O.build()
+    O.lib()
+    cores = len(os.sched_getaffinity(0))
+    p = O.default_params(nfeatures)
+    done = [0] * cores
+    t_end = time.time() + budget_s
+
+    def work(t):
+        seed = 1 + t
+        a, b = A.synth_frame_pair(seed, width, height)
+        _, prev = O.orb_extract(a, p)
+        cur_img = b
+        while True:
+            _, cur = O.orb_extract(cur_img, p)
+            O.match_ratio(cur, prev, 0.75)
+            done[t] += 1
+            prev = cur
+            if time.time() >= t_end:
+                break
+            seed += cores
+            a, b = A.synth_frame_pair(seed, width, height)
+            cur_img = a if (done[t] & 1) else b
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt = time.time() - t0
+    n = sum(done)
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames (1 extract + 1 match each) of the same synthetic %dx%d/%d-kp workload in %.1f s, "
+                      "%d threads; port = oracle/orb_oracle.cpp (scalar C++ restatement of OpenCV CPU ORB + BFMatcher)"
+                      % (n, width, height, nfeatures, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=4096, help="frame pairs per GPU (sequence length = 2*pairs)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--chunk", type=int, default=256, help="frames per internal extractor pass")
+    ap.add_argument("--ratio", type=float, default=0.75)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import aria_slam_amd as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    n_gpus = world
+
+    A.load_library()
+    W, H, NF = args.width, args.height, args.features
+    B = 2 * args.pairs
+
+    # ---- synthetic sequence shard of this rank, resident in HBM before timing ----
+    host = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=False)
+    A.synth_sequence(1 + rank * args.pairs, args.pairs, W, H, out=host.numpy())
+    images = host.to(dev)
+    del host
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ext = A.OrbHipExtractor(max_features=NF, stream=stream, device=dev.index, max_width=W, max_height=H,
+                            max_batch=args.chunk)
+    mat = A.HipMatcher(stream=stream, device=dev.index, max_query=4096, max_train=4096)
+    cap = ext.kp_capacity()
+    kps = torch.empty((B, cap, 24), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+    halo_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+    halo_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    matches = torch.empty((B, cap, 12), dtype=torch.uint8, device=dev)
+    nmatches = torch.zeros((B,), dtype=torch.int32, device=dev)
+    dstride = cap * 32
+
+    def step():
+        halo_desc.copy_(desc[B - 1])
+        halo_cnt.copy_(counts[B - 1:B])
+        ext.extract_batch_device(images, B, W, H, kps, desc, counts, cap)
+        mat.match_batch_device(desc, counts, halo_desc, halo_cnt, 1, dstride, args.ratio, matches, nmatches, cap)
+        mat.match_batch_device(desc.data_ptr() + dstride, counts.data_ptr() + 4, desc, counts, B - 1, dstride,
+                               args.ratio, matches.data_ptr() + cap * 12, nmatches.data_ptr() + 4, cap)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ext.check()
+    mat.sync()
+    ext.set_profiling(True)
+    mat.set_profiling(True)
+    ext.get_profile(reset=True)
+    mat.get_profile(reset=True)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ext.check()
+    mat.sync()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    prof_e, prof_frames = ext.get_profile(reset=True)
+    prof_m, prof_pairs = mat.get_profile(reset=True)
+    cnt_host = counts.cpu().numpy()
+    nm_host = nmatches.cpu().numpy()
+
+    if rank == 0:
+        frames_total = B * args.steps * n_gpus
+        value = frames_total / dt
+        # ---- roofline of the dominant kernel, from HIP events on the launch stream ----
+        stage_ms = {k: v[0] for k, v in prof_e.items()}
+        stage_ms.update({k: v[0] for k, v in prof_m.items()})
+        launches = {k: v[1] for k, v in prof_e.items()}
+        launches.update({k: v[1] for k, v in prof_m.items()})
+        b_extract, b_fused = ext.algorithmic_bytes(W, H, NF)
+        P = (b_fused - 56 * NF) // 2
+        # algorithmic bytes per frame of each extractor kernel (DESIGN.md "Kernels")
+        p0 = W * H
+        lv = ext.level_info(W, H)
+        p7 = lv[7][0] * lv[7][1]
+        alg = {"resize": (P - p7) + (P - p0), "fast_blur": 2 * P, "describe": 56 * NF}
+        dom = max(("resize", "fast_blur", "select", "describe"), key=lambda k: stage_ms[k])
+        fb_ms_per_launch = stage_ms["fast_blur"] / max(launches["fast_blur"], 1)
+        frames_per_launch = prof_frames / max(launches["fast_blur"], 1)
+        fb_bytes_per_launch = alg["fast_blur"] * frames_per_launch
+        achieved = fb_bytes_per_launch / (fb_ms_per_launch * 1e-3) / 1e9 if fb_ms_per_launch > 0 else 0.0
+        ext_ms = sum(stage_ms[k] for k in ("resize", "fast_blur", "select", "describe"))
+        roofline = {
+            "bound": "hbm", "kernel": "k_fast_blur (FAST-9 + NMS + 7x7 Gaussian, fused on one LDS tile)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": int(fb_bytes_per_launch),
+            "avg_launch_ms": round(fb_ms_per_launch, 4), "frames_per_launch": frames_per_launch,
+            "dominant_stage": dom,
+            "whole_extractor": {"algorithmic_bytes_per_frame": b_extract,
+                                "achieved_GBs": round(b_extract * prof_frames / (ext_ms * 1e-3) / 1e9, 1) if ext_ms else None,
+                                "frac": round(b_extract * prof_frames / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_ms else None},
+            "stage_us_per_frame": {k: round(1e3 * stage_ms[k] / max(prof_frames, 1), 3) for k in stage_ms},
+            "matcher_popcount_dwords_per_s": round(8.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))
+                                                   * args.steps / (stage_ms["knn2"] * 1e-3), 1) if stage_ms["knn2"] else None,
+        }
+        out = {
+            "metric": "frames/s ORB extract+BF-match, 640x480 @2000 kp" if (W, H, NF) == (640, 480, 2000)
+                      else "frames/s ORB extract+BF-match, %dx%d @%d kp" % (W, H, NF),
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: sequence of %d synthetic %dx%d frame pairs per GPU "
+                                   "(%d frames), %d kp/frame, 1 extract + 1 kNN-2/ratio match per frame, inputs "
+                                   "resident in HBM" % (args.pairs, W, H, B, NF),
+                       "frames_per_gpu_per_step": B, "chunk_frames": args.chunk, "ratio": args.ratio,
+                       "parallelism": "frames sharded by contiguous range, %d rank(s), no collective" % n_gpus,
+                       "mean_keypoints_per_frame": round(float(cnt_host.mean()), 2),
+                       "mean_matches_per_frame": round(float(nm_host.mean()), 2)},
+            "roofline": roofline,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, NF, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+
+    ext.close()
+    mat.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

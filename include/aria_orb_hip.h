@@ -113,6 +113,15 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
 int aria_orb_check(aria_orb_t h);
 void* aria_orb_stream(aria_orb_t h);
 
+/* Per-stage device timing for bench.py's roofline figure (no reference counterpart): when enabled, HIP events
+ * are recorded on the handle's stream around each stage of every internal pass.
+ * Stages: 0 pyramid resize (7 launches per pass), 1 FAST+NMS+blur, 2 select (retainBest+Harris), 3 describe
+ * (IC angle + rBRIEF). get_profile synchronises the stream; times are summed milliseconds since the last reset. */
+#define ARIA_ORB_STAGES 4
+int aria_orb_set_profiling(aria_orb_t h, int enable);
+int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms /*[4]*/, int64_t* stage_launches /*[4]*/,
+                         int64_t* frames);
+
 /* Introspection for parity tests and benchmarks (no reference counterpart): pyramid geometry, and copies
  * of frame 0's intermediate buffers of the most recent call. level in [0, 8). */
 int aria_orb_level_info(aria_orb_t h, int width, int height, int level, int* lw, int* lh, int* quota, float* scale);
@@ -162,6 +171,11 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
  * Scoring/top-5 (LoopClosure.cpp:98-111) is host logic in the adapter. */
 int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int nq, const uint8_t* d_db,
                          const int* d_kf_counts, int n_kf, int64_t desc_stride, double ratio, int* d_good);
+/* Same for the matcher: stage 0 = kNN-2 kernel, stage 1 = ratio test + ordered compaction. */
+#define ARIA_MATCHER_STAGES 2
+int aria_matcher_set_profiling(aria_matcher_t m, int enable);
+int aria_matcher_get_profile(aria_matcher_t m, int reset, double* stage_ms /*[2]*/, int64_t* stage_launches /*[2]*/,
+                             int64_t* pairs);
 void* aria_matcher_stream(aria_matcher_t m);
 int   aria_matcher_sync(aria_matcher_t m);
 
