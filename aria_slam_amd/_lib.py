@@ -24,7 +24,7 @@ EXPORTS = [
     "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_extract", "aria_orb_extract_async",
     "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream",
     "aria_orb_set_profiling", "aria_orb_get_profile", "aria_matcher_set_profiling", "aria_matcher_get_profile",
-    "aria_orb_level_info", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
+    "aria_orb_level_info", "aria_orb_resize_table", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
     "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
     "aria_matcher_knn2", "aria_matcher_match_batch_device", "aria_matcher_match_db_device",
     "aria_matcher_stream", "aria_matcher_sync", "aria_synth_frame_pair", "aria_synth_sequence",
@@ -97,11 +97,11 @@ def load_library():
     L.aria_orb_set_max_features.argtypes = [C.c_void_p, C.c_int]
     L.aria_orb_get_max_features.argtypes = [C.c_void_p]
     L.aria_orb_kp_capacity.argtypes = [C.c_void_p]
-    L.aria_orb_level_info.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+    L.aria_orb_level_info.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.aria_orb_resize_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.aria_orb_debug_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    L.aria_orb_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
-                                             C.POINTER(C.c_int64)]
+    L.aria_orb_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.aria_matcher_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_int)]
     L.aria_matcher_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -134,6 +134,34 @@ def abi_version():
 def check(status, where):
     if status != ARIA_OK:
         raise AriaError(status, where)
+
+
+def level_info(max_features, width, height):
+    """[(level_width, level_height, quota, scale)] x 8 -- host-only plan geometry."""
+    L = load_library()
+    out = []
+    for l in range(8):
+        lw, lh, q, s = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        check(L.aria_orb_level_info(max_features, width, height, l, C.byref(lw), C.byref(lh), C.byref(q), C.byref(s)),
+              "aria_orb_level_info")
+        out.append((lw.value, lh.value, q.value, s.value))
+    return out
+
+
+def resize_table(width, height, level, axis):
+    """(offsets, next-pixel weights in 1/256) of the INTER_LINEAR_EXACT table of `level` along `axis`."""
+    buf = np.zeros(4096, np.uint32)
+    n = load_library().aria_orb_resize_table(width, height, level, axis, buf.ctypes.data, len(buf))
+    if n < 0:
+        raise AriaError(n, "aria_orb_resize_table")
+    return (buf[:n] & 0xFFFF).astype(np.int32), (buf[:n] >> 16).astype(np.int32)
+
+
+def algorithmic_bytes(width, height, n_keypoints):
+    be, bf = C.c_int64(), C.c_int64()
+    check(load_library().aria_orb_algorithmic_bytes(width, height, n_keypoints, C.byref(be), C.byref(bf)),
+          "aria_orb_algorithmic_bytes")
+    return be.value, bf.value
 
 
 def synth_frame_pair(seed, width=640, height=480):

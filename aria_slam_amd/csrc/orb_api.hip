@@ -338,18 +338,31 @@ int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms, int64_t* sta
     return ARIA_OK;
 }
 
-int aria_orb_level_info(aria_orb_t h, int width, int height, int level, int* lw, int* lh, int* quota, float* scale) {
-    if (!h || level < 0 || level >= kLevels) return ARIA_E_INVALID;
+int aria_orb_level_info(int max_features, int width, int height, int level, int* lw, int* lh, int* quota, float* scale) {
+    if (level < 0 || level >= kLevels) return ARIA_E_INVALID;
     Plan p;
     std::vector<uint32_t> tab((size_t)plan_tab_entries(width, height) + 64);
     int used = 0;
-    int rc = build_plan(width, height, h->max_features, h->cand_cap_scale, h->tie_mode, &p, tab.data(), (int)tab.size(), &used);
+    int rc = build_plan(width, height, max_features, 0, 1, &p, tab.data(), (int)tab.size(), &used);
     if (rc != ARIA_OK) return rc;
     if (lw) *lw = p.lv[level].w;
     if (lh) *lh = p.lv[level].h;
     if (quota) *quota = p.lv[level].quota;
     if (scale) *scale = p.lv[level].scale;
     return ARIA_OK;
+}
+
+int aria_orb_resize_table(int width, int height, int level, int axis, uint32_t* out, int cap) {
+    if (level < 1 || level >= kLevels || !out || (axis != 0 && axis != 1)) return ARIA_E_INVALID;
+    Plan p;
+    std::vector<uint32_t> tab((size_t)plan_tab_entries(width, height) + 64);
+    int used = 0;
+    int rc = build_plan(width, height, 1000, 0, 1, &p, tab.data(), (int)tab.size(), &used);
+    if (rc != ARIA_OK) return rc;
+    const int n = axis == 0 ? p.lv[level].w : p.lv[level].h;
+    if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
+    std::memcpy(out, tab.data() + (axis == 0 ? p.lv[level].xtab : p.lv[level].ytab), sizeof(uint32_t) * (size_t)n);
+    return n;
 }
 
 int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* host_out) {
@@ -366,12 +379,11 @@ int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* hos
     return ARIA_OK;
 }
 
-int aria_orb_algorithmic_bytes(aria_orb_t h, int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused) {
-    if (!h) return ARIA_E_INVALID;
+int aria_orb_algorithmic_bytes(int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused) {
     Plan p;
     std::vector<uint32_t> tab((size_t)plan_tab_entries(width, height) + 64);
     int used = 0;
-    int rc = build_plan(width, height, h->max_features, h->cand_cap_scale, h->tie_mode, &p, tab.data(), (int)tab.size(), &used);
+    int rc = build_plan(width, height, 1000, 0, 1, &p, tab.data(), (int)tab.size(), &used);
     if (rc != ARIA_OK) return rc;
     const int64_t P = p.pixels_total;
     const int64_t p0 = (int64_t)p.lv[0].w * p.lv[0].h, p7 = (int64_t)p.lv[kLevels - 1].w * p.lv[kLevels - 1].h;

@@ -132,13 +132,7 @@ class OrbHipExtractor:
 
     # ---- introspection for parity tests ----
     def level_info(self, width, height):
-        out = []
-        for l in range(8):
-            lw, lh, q, s = C.c_int(), C.c_int(), C.c_int(), C.c_float()
-            check(self._L.aria_orb_level_info(self._h, width, height, l, C.byref(lw), C.byref(lh), C.byref(q),
-                                              C.byref(s)), "aria_orb_level_info")
-            out.append((lw.value, lh.value, q.value, s.value))
-        return out
+        return _lib.level_info(self.getMaxFeatures(), width, height)
 
     def debug_read_level(self, level, blurred, lw, lh):
         out = np.empty((lh, lw), np.uint8)
@@ -147,10 +141,7 @@ class OrbHipExtractor:
         return out
 
     def algorithmic_bytes(self, width, height, n_keypoints):
-        be, bf = C.c_int64(), C.c_int64()
-        check(self._L.aria_orb_algorithmic_bytes(self._h, width, height, n_keypoints, C.byref(be), C.byref(bf)),
-              "aria_orb_algorithmic_bytes")
-        return be.value, bf.value
+        return _lib.algorithmic_bytes(width, height, n_keypoints)
 
     @staticmethod
     def _fill(frame, width, height, kps, desc):

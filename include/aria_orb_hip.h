@@ -122,12 +122,17 @@ int aria_orb_set_profiling(aria_orb_t h, int enable);
 int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms /*[4]*/, int64_t* stage_launches /*[4]*/,
                          int64_t* frames);
 
-/* Introspection for parity tests and benchmarks (no reference counterpart): pyramid geometry, and copies
- * of frame 0's intermediate buffers of the most recent call. level in [0, 8). */
-int aria_orb_level_info(aria_orb_t h, int width, int height, int level, int* lw, int* lh, int* quota, float* scale);
-int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* host_out /* lw*lh, packed */);
+/* Introspection for parity tests and benchmarks (no reference counterpart).
+ * Host-only geometry (no handle, no GPU needed): size, quota and scale of pyramid level `level` in [0, 8) for
+ * a width x height image, as CPU cv::ORB lays it out; and the fixed-point INTER_LINEAR_EXACT coefficient table
+ * of level >= 1 along axis 0 (x) or 1 (y): entry d = source offset | (weight_of_next_pixel_in_1/256 << 16).
+ * aria_orb_resize_table returns the number of entries written (or a negative status). */
+int aria_orb_level_info(int max_features, int width, int height, int level, int* lw, int* lh, int* quota, float* scale);
+int aria_orb_resize_table(int width, int height, int level, int axis, uint32_t* out, int cap);
 /* Algorithmic bytes of one frame: b_extract = 5P - p0 - p7 + 56N, b_fused = 2P + 56N. */
-int aria_orb_algorithmic_bytes(aria_orb_t h, int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused);
+int aria_orb_algorithmic_bytes(int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused);
+/* Copies level `level` (raw or blurred) of frame 0 of the most recent call to host memory (lw*lh bytes, packed). */
+int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* host_out);
 
 /* ---- matcher: replaces CudaMatcher (include/adapters/gpu/CudaMatcher.hpp, src/adapters/gpu/CudaMatcher.cpp) -- */
 typedef struct {

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/golden.json.
+
+There is nothing to import from the reference (its hot path is OpenCV calls and OpenCV is absent), so these
+goldens are produced by THIS repo's CPU oracle on seeded synthetic frames. They pin (a) the synthetic generator,
+(b) the oracle against accidental change, and (c) give the GPU tests a fixture that does not need the oracle
+at run time. They do NOT pin the oracle against real OpenCV (parity unpinned, see oracle/orb_oracle.h).
+
+Usage: python tests/golden/make_golden.py   (rewrites golden.json and golden_seed1_640x480.npz)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import aria_slam_amd as A            # noqa: E402  (generator only; no GPU needed)
+from oracle import oracle_py as O    # noqa: E402
+
+
+def sha(x):
+    return hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
+
+
+def main():
+    g = {}
+    a, b = A.synth_frame_pair(1, 640, 480)
+    g["synth_seed1_a"], g["synth_seed1_b"] = sha(a), sha(b)
+    cases = [(1, 640, 480, 2000), (2, 640, 480, 2000), (7, 752, 480, 1000), (3, 333, 251, 300), (11, 1408, 1408, 4000)]
+    for seed, w, h, nf in cases:
+        fa, fb = A.synth_frame_pair(seed, w, h)
+        p = O.default_params(nf)
+        ka, da = O.orb_extract(fa, p)
+        kb, db = O.orb_extract(fb, p)
+        m = O.match_ratio(db, da, 0.75)
+        key = "s%d_%dx%d_n%d" % (seed, w, h, nf)
+        g[key] = {"image_a": sha(fa), "image_b": sha(fb), "n_a": len(ka), "n_b": len(kb),
+                  "kp_a": sha(ka), "desc_a": sha(da), "kp_b": sha(kb), "desc_b": sha(db),
+                  "n_matches": len(m), "matches": sha(m),
+                  "per_level_a": np.bincount(ka["octave"], minlength=8).tolist(),
+                  "first_kp_a": [float(ka[0][f]) for f in ("x", "y", "size", "angle", "response")] + [int(ka[0]["octave"])],
+                  "first_desc_a": da[0].tolist()}
+        if (seed, w, h) == (1, 640, 480):
+            np.savez_compressed(os.path.join(HERE, "golden_seed1_640x480.npz"), kp_a=ka, desc_a=da, kp_b=kb,
+                                desc_b=db, matches=m)
+    json.dump(g, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
+    print("wrote", os.path.join(HERE, "golden.json"))
+
+
+if __name__ == "__main__":
+    main()
