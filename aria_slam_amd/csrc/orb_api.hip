@@ -26,7 +26,7 @@ struct aria_orb_s {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 32;
+    int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 0;
 
     Plan plan{};            // plan of the most recent (width, height)
     bool plan_valid = false;
@@ -209,7 +209,7 @@ int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
     h->max_features = c->max_features;
     h->max_batch = c->max_batch;
     h->tie_mode = c->blur_tie_mode ? 1 : 0;
-    h->cand_cap_scale = c->cand_cap_scale > 0 ? c->cand_cap_scale : 32;
+    h->cand_cap_scale = c->cand_cap_scale > 0 ? c->cand_cap_scale : 0;
     if (c->stream) {
         h->stream = (hipStream_t)c->stream;
     } else {

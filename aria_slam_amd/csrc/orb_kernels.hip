@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint2* __restrict__ sel, int* __restrict__ sel_cnt,
                                                 int* __restrict__ err) {
-    __shared__ unsigned long long s_keys[kSortCap];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
     __shared__ int s_hist[256];
     __shared__ int s_misc[4];   // [0] threshold score, [1] n1, [2] n2
 
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
     const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
     const int q = g.quota;
+    const int kSortCap = P.sort_cap;
 
     if (q == 0 || n == 0) {   // retainBest(keypoints, 0) clears
         if (tid == 0) sel_cnt[frame * kLevels + l] = 0;
@@ -562,6 +563,12 @@ void Profiler::release() {
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
                           Profiler* prof) {
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // k_select may need more than the default 64 KB of dynamic LDS for very large quotas
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(unsigned long long) * kSortCapMax));
+        lds_attr_set = true;
+    }
     const bool pr = prof && prof->enabled;
     StageEvents se;
     se.n_frames = n_frames;
@@ -577,7 +584,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     hipLaunchKernelGGL(k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur, D.cand,
                        D.cand_cnt, D.err);
     if (pr) hipEventRecord(se.ev[2], st);
-    hipLaunchKernelGGL(k_select, dim3(kLevels, n_frames), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel,
+    hipLaunchKernelGGL(k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel,
                        D.sel_cnt, D.err);
     if (pr) hipEventRecord(se.ev[3], st);
     hipLaunchKernelGGL(k_describe, dim3((P.sel_frame_entries + 3) / 4, n_frames), dim3(256), 0, st, P, S, D.raw,

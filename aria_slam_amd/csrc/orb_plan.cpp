@@ -53,7 +53,6 @@ int64_t plan_tab_entries(int width, int height) {
 int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie_mode, Plan* P,
                uint32_t* tab, int tab_capacity, int* tab_used) {
     if (width < 16 || height < 16 || width > kMaxDim || height > kMaxDim || nfeatures < 0) return ARIA_E_INVALID;
-    if (cand_cap_scale <= 0) cand_cap_scale = 32;
     *P = Plan{};
     P->width = width;
     P->height = height;
@@ -88,7 +87,9 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
         g.quota = quota[l];
         // worst case after 3x3 strict-max suppression is one corner per 2x2 block of the kept region
         int region = std::max(g.w - 2 * kEdgeThreshold, 0) * std::max(g.h - 2 * kEdgeThreshold, 0);
-        g.cand_cap = std::max(256, std::min(region / 4 + 64, cand_cap_scale * std::max(quota[l], 1)));
+        // default: the worst case itself, so the list can never overflow; cand_cap_scale > 0 trades that for memory
+        const int worst = region / 4 + 64;
+        g.cand_cap = cand_cap_scale <= 0 ? worst : std::max(256, std::min(worst, cand_cap_scale * std::max(quota[l], 1)));
         g.cand_off = cand;
         cand += g.cand_cap;
         g.sel_cap = quota[l] + kSelSlack;
@@ -113,6 +114,11 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
             tabpos += g.h;
         }
     }
+    // LDS sort capacity of k_select: room for retainBest(2*quota) plus ties at the cut, power of two
+    int sc = kSortCapMin;
+    while (sc < 2 * quota[0] + 1024 && sc < kSortCapMax) sc <<= 1;
+    if (2 * quota[0] + 64 > kSortCapMax) return ARIA_E_INVALID;   // nfeatures beyond what one workgroup can rank
+    P->sort_cap = sc;
     P->total_tiles = tile;
     P->cand_frame_entries = cand;
     P->sel_frame_entries = sel;

@@ -20,7 +20,8 @@ constexpr int kHalo = 4;
 constexpr int kPatchW = kTileW + 2 * kHalo;  // 72
 constexpr int kPatchH = kTileH + 2 * kHalo;  // 40
 
-constexpr int kSortCap = 4096;   // LDS bitonic sort capacity of the per-(frame,level) selection kernel
+constexpr int kSortCapMin = 4096;    // LDS bitonic sort capacity of the per-(frame,level) selection kernel (entries of 8 B)
+constexpr int kSortCapMax = 16384;   // 128 KB of the CU's 160 KB LDS
 constexpr int kSelSlack = 64;    // extra output slots per level for ties at the Harris cut
 constexpr int kMaxDim = 2047;    // candidate packing: x:11 | y:11 | score:8
 
@@ -50,6 +51,8 @@ struct Plan {
     int sel_frame_entries;    // selection entries per frame (all levels)
     int tie_mode;
     int fast_threshold;
+    int sort_cap;             // power of two in [kSortCapMin, kSortCapMax]
+    int _pad2;
     int64_t raw_frame_bytes;
     int64_t blur_frame_bytes;
     int64_t pixels_total;     // P of BASELINE.md section 3

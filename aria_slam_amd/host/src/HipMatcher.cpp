@@ -1,0 +1,85 @@
+// See aria_hip/HipMatcher.hpp. Mirrors src/adapters/gpu/CudaMatcher.cpp:28-68 and
+// src/legacy/LoopClosure.cpp:72-114 of the reference.
+#include "aria_hip/HipMatcher.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+
+#include "aria_orb_hip.h"
+
+namespace aria::adapters::hip {
+
+static_assert(sizeof(core::Match) == sizeof(aria_match), "Match must stay 12 bytes (Types.hpp:97-101)");
+
+namespace {
+[[noreturn]] void fail(const char* where, int status) {
+    std::string msg = std::string("HipMatcher: ") + where + ": " + aria_status_string(status);
+    const char* hip = aria_last_hip_error();
+    if (hip && hip[0]) msg += std::string(" [") + hip + "]";
+    throw std::runtime_error(msg);
+}
+}  // namespace
+
+HipMatcher::HipMatcher(void* stream, int device) : stream_(stream), device_(device) {}
+HipMatcher::~HipMatcher() { aria_matcher_destroy(m_); }
+
+void HipMatcher::ensure(int nq, int nt) {
+    if (m_ && nq <= cap_q_ && nt <= cap_t_) return;
+    aria_matcher_destroy(m_);
+    m_ = nullptr;
+    aria_matcher_config cfg;
+    aria_matcher_default_config(&cfg);
+    cfg.device = device_;
+    cfg.stream = stream_;
+    cfg.max_query = std::max({nq, cap_q_, 4096});
+    cfg.max_train = std::max({nt, cap_t_, 4096});
+    int rc = aria_matcher_create(&cfg, &m_);
+    if (rc != ARIA_OK) fail("aria_matcher_create", rc);
+    cap_q_ = cfg.max_query;
+    cap_t_ = cfg.max_train;
+}
+
+void HipMatcher::match(const core::Frame& query, const core::Frame& train, std::vector<core::Match>& matches,
+                       float ratio_threshold) {
+    if (query.descriptors.empty() || train.descriptors.empty()) return;        // CudaMatcher.cpp:35-37
+    const int nq = (int)query.numKeypoints(), nt = (int)train.numKeypoints();   // :41-42 rows = numKeypoints()
+    if ((size_t)nq * 32 > query.descriptors.size() || (size_t)nt * 32 > train.descriptors.size())
+        fail("match: descriptors shorter than numKeypoints()*32", ARIA_E_INVALID);
+    ensure(nq, nt);
+    buf_.resize((size_t)std::max(nq, 1));
+    int n = 0;
+    int rc = aria_matcher_match(m_, query.descriptors.data(), nq, train.descriptors.data(), nt, ratio_threshold,
+                                reinterpret_cast<aria_match*>(buf_.data()), (int)buf_.size(), &n);
+    if (rc != ARIA_OK) fail("aria_matcher_match", rc);
+    matches.insert(matches.end(), buf_.begin(), buf_.begin() + n);            // :65 push_back, never cleared
+}
+
+std::vector<std::pair<int, double>> HipMatcher::findLoopCandidates(const core::Frame& query,
+                                                                  const std::vector<core::Frame>& keyframes,
+                                                                  int min_frames_between) {
+    std::vector<std::pair<int, double>> candidates;
+    if (query.descriptors.empty()) return candidates;                          // LoopClosure.cpp:75
+    const int nq = (int)query.numKeypoints();
+    for (size_t i = 0; i < keyframes.size(); i++) {
+        const core::Frame& kf = keyframes[i];
+        if ((long long)query.id - (long long)kf.id < (long long)min_frames_between) continue;   // :81
+        if (kf.descriptors.empty()) continue;                                  // :83
+        const int nt = (int)kf.numKeypoints();
+        ensure(nq, nt);
+        std::vector<int> idx((size_t)nq * 2), dist((size_t)nq * 2);
+        int rc = aria_matcher_knn2(m_, query.descriptors.data(), nq, kf.descriptors.data(), nt, idx.data(), dist.data());
+        if (rc != ARIA_OK) fail("aria_matcher_knn2", rc);
+        int good = 0;
+        for (int q = 0; q < nq; q++)                                           // :90-95, double literal 0.7
+            if (idx[2 * q + 1] >= 0 && (double)(float)dist[2 * q] < 0.7 * (double)(float)dist[2 * q + 1]) good++;
+        const double score = (double)good / std::max(1, nq);                  // :98
+        if (score > 0.1) candidates.push_back({(int)i, score});                // :99
+    }
+    std::stable_sort(candidates.begin(), candidates.end(),
+                     [](const auto& a, const auto& b) { return a.second > b.second; });   // :105-106
+    if (candidates.size() > 5) candidates.resize(5);                           // :109-111
+    return candidates;
+}
+
+}  // namespace aria::adapters::hip

@@ -66,7 +66,8 @@ typedef struct {
     int   max_features;    /* nfeatures (OrbCudaExtractor.hpp:12 default 1000)                              */
     int   max_batch;       /* frames processed per internal pass of the batch entry point (>= 1)            */
     int   blur_tie_mode;   /* 1 (default): OpenCV SIMD column-filter rounding; 0: ties-up everywhere        */
-    int   cand_cap_scale;  /* per-level candidate buffer = cand_cap_scale * quota entries (0 = default 32)  */
+    int   cand_cap_scale;  /* 0 (default): FAST candidate lists sized for the worst case, cannot overflow;
+                              > 0: cap each level's list at cand_cap_scale * quota entries to save HBM          */
 } aria_orb_config;
 
 const char* aria_status_string(int status);

@@ -1,0 +1,67 @@
+"""The C++ adapters (aria_slam_amd/host) implementing the reference's IFeatureExtractor / IMatcher ports."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "aria_slam_amd")
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_selftest")
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in bytes(b):
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+@pytest.fixture(scope="module")
+def selftest(aria):
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host"), "-s"])
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_selftest.cpp")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(PKG, "libaria_hip_adapters.so"))):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(PKG, "host", "include"), src, "-o", EXE, "-L" + PKG,
+                               "-laria_hip_adapters", "-laria_orb_hip", "-Wl,-rpath," + PKG])
+    return EXE
+
+
+def test_adapters_fail_loudly_without_gpu(selftest):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([selftest, "nogpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK nogpu" in out.stdout and "no usable HIP device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_adapters_equal_python_binding_and_reference_conventions(aria, selftest):
+    out = subprocess.run([selftest, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "DONE" in out.stdout, out.stdout + out.stderr
+    kv = {}
+    for line in out.stdout.splitlines():
+        t = line.split()
+        kv[t[0]] = t[1:]
+    a, b = aria.synth_frame_pair(1, 640, 480)
+    e = aria.OrbHipExtractor(max_features=2000)
+    m = aria.HipMatcher()
+    fa, fb = e.extract(a), e.extract(b)
+    assert kv["n_a"] == [str(len(fa["keypoints"])), "n_b", str(len(fb["keypoints"]))]
+    assert kv["kp_a"] == [_fnv(fa["keypoints"].tobytes()), "desc_a", _fnv(fa["descriptors"].tobytes())]
+    assert kv["kp_b"] == [_fnv(fb["keypoints"].tobytes()), "desc_b", _fnv(fb["descriptors"].tobytes())]
+    assert kv["async_same"] == ["1"]
+    mm = m.match(fb, fa)
+    assert kv["n_matches"] == [str(len(mm)), "first_kept", "1"]            # append semantics (CudaMatcher.cpp:65)
+    assert kv["matches"] == [_fnv(mm.tobytes())]
+    assert kv["empty_untouched"] == ["1"]                                  # CudaMatcher.cpp:35-37
+    assert kv["multi"] == ["3", str(len(mm)), str(len(m.match(fb, fb))), "0"]   # IMatcher.hpp:33 resize + loop
+    e.setMaxFeatures(500)
+    f5 = e.extract(a)
+    assert kv["n_500"] == [str(len(f5["keypoints"])), "max", "500"]
+    assert kv["kp_500"] == [_fnv(f5["keypoints"].tobytes()), "desc_500", _fnv(f5["descriptors"].tobytes())]
+    assert kv["loop"][0] == "1" and float(kv["loop"][1]) > 0.1
+    e.close()
+    m.close()
