@@ -1,0 +1,464 @@
+// k_fast_blur_band: FAST-9/16 + NMS + 7x7 Gaussian for one horizontal band (16 rows x full level width) of one
+// pyramid level of one frame per workgroup.  SURVEY.md rows a6.2 (FAST), a6.3 (border filter), a6.7 (blur).
+//
+// Why this shape (MI355X):
+//  * one lane owns a 4-pixel column strip and walks DOWN the band with a 7-row window in registers, so every staged
+//    pixel is read from LDS once as part of an aligned dword (3 ds_read_b32 per 4 px per row) instead of ~45 byte
+//    reads per pixel; rows are full level rows, so global loads/stores are fully coalesced 256-B wave rows and
+//    there is no horizontal halo to recompute;
+//  * the horizontal 7-tap pass is two v_dot4_u32_u8 per pixel on byte-shifted dwords (v_alignbyte_b32); the
+//    vertical pass is 7 integer MADs on the register window;
+//  * FAST is split: a 4-point compass reject in packed-16 arithmetic on every pixel (a 9-arc always contains one of
+//    each antipodal compass pair), survivors (~8 % of pixels) are appended to an LDS queue and scored DENSELY
+//    afterwards (all lanes busy) with the (d, -d) packed min-tree -- score >= threshold <=> FAST-9 corner;
+//  * 3x3 strict-max NMS runs only over scored corners, candidates leave through a wave-aggregated append
+//    (ballot + popcount prefix, one global atomic per wave).
+// Integer/byte work only: no MFMA. Results are bit-identical to the tile kernel it replaces (tests/test_gpu_*).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "orb_device.h"
+#include "orb_kernels.h"
+
+namespace aria {
+
+constexpr int kBandR = 32;                 // output rows per strip (one lane walks R + 8 staged rows)
+constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a strip
+
+// Workgroup geometry for a level of width w: NB vertically stacked strips of R rows share one staged block of
+// NB*R + 8 rows; thread = (strip, 4-px column). NB is chosen so the waves are full even on narrow levels.
+struct BandCfg { int nb, lpr, nthr, qcap; size_t lds; };
+static BandCfg band_cfg(int w) {
+    // LDS budget per workgroup: 48 KB keeps >= 3 workgroups resident per CU. The survivor queue gets whatever the
+    // staged pixels leave, capped at 50 % of the block's pixels (coarse pyramid levels are corner-dense: the compass
+    // test passes 3 % of level-0 pixels but 25-30 % at level 7 on the benchmark frames); it must hold >= 25 %.
+    const size_t budget = 48 * 1024;
+    const int wq = (w + 3) & ~3, lpr = wq >> 2;
+    BandCfg best{};
+    double best_util = -1.0;
+    for (int nb = 1; nb <= 8; nb++) {
+        const int need = nb * lpr, nthr = ((need + 63) / 64) * 64;
+        if (nthr > 512) break;
+        const size_t pix = (size_t)(nb * kBandR + 8) * (wq + 8);
+        const int px_blk = nb * kBandR * wq;
+        int qcap = px_blk / 2;
+        if (pix + 4 * (size_t)qcap > budget) qcap = pix < budget ? (int)((budget - pix) / 4) : 0;
+        qcap &= ~63;
+        if (nb > 1 && qcap < px_blk / 4) break;
+        if (qcap < 1024) qcap = 1024;                          // very wide levels: a single strip, whatever it costs
+        const double util = (double)need / nthr;
+        if (util > best_util + 0.02) { best_util = util; best = BandCfg{nb, lpr, nthr, qcap, pix + 4 * (size_t)qcap}; }
+    }
+    return best;
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b));
+}
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) + __builtin_bit_cast(short2v, b));
+}
+
+// fast_score.cpp cornerScore<16> for the pixel at LDS address c (row pitch `pitch`):
+// max over the 16 nine-arcs of min(v - ring) and of min(ring - v), minus 1; both polarities ride in one register as
+// packed int16 (lo = v - p, hi = p - v). The pixel is a FAST-9 corner for threshold t iff the result is >= t.
+__device__ __forceinline__ int fast_score_pk(const uint8_t* c, int pitch) {
+    const uint8_t* rm3 = c - 3 * pitch; const uint8_t* rm2 = c - 2 * pitch; const uint8_t* rm1 = c - pitch;
+    const uint8_t* rp1 = c + pitch; const uint8_t* rp2 = c + 2 * pitch; const uint8_t* rp3 = c + 3 * pitch;
+    const uint32_t v = c[0];
+    const uint32_t vhi = v << 16;
+    uint32_t ring[16] = {rp3[0], rp3[1], rp2[2], rp1[3], c[3], rm1[3], rm2[2], rm3[1],
+                         rm3[0], rm3[-1], rm2[-2], rm1[-3], c[-3], rp1[-3], rp2[-2], rp3[-1]};
+    uint32_t P[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) P[k] = pk_sub_i16(v | (ring[k] << 16), ring[k] | vhi);
+    uint32_t M2[16], M4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M2[k] = pk_min_i16(P[k], P[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) M4[k] = pk_min_i16(M2[k], M2[(k + 2) & 15]);
+    uint32_t Q = 0x80008000u;   // (-32768, -32768)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t m9 = pk_min_i16(pk_min_i16(M4[k], M4[(k + 4) & 15]), P[(k + 8) & 15]);
+        Q = pk_max_i16(Q, m9);
+    }
+    const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
+    return max(q0, q1) - 1;
+}
+
+template <int TIE_EVEN>
+__global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                        uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
+                                                        int* __restrict__ cand_cnt, int* __restrict__ err, int l,
+                                                        int nb, int qcap, int ablate, unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_qn, s_ovf;
+    // diagnostic build only (ARIA_STAMPS=1): phase boundaries of wave 0 of every workgroup, s_memtime ticks
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
+
+    const LevelGeom g = P.lv[l];
+    const int w = g.w, h = g.h;
+    const int wq = (w + 3) & ~3;
+    const int lpr = wq >> 2;                             // lanes per row
+    const int pitchL = wq + 8;                           // LDS pitch of the staged block: column 0 <-> x = -4
+    const int sp = wq + 4;                               // score-map pitch: column 0 <-> x = -1
+    const int RB = nb * kBandR;                          // output rows of this workgroup
+    const int rowsL = RB + 8;                            // staged rows y0-4 .. y0+RB+3
+    uint8_t* s_pix = smem;
+    uint8_t* s_map = smem;                               // score map, aliases s_pix once the pixels are dead
+    uint32_t* s_queue = reinterpret_cast<uint32_t*>(smem + rowsL * pitchL);
+
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int frame = blockIdx.y;
+    const int y0 = blockIdx.x * RB;
+    int pitch;
+    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
+
+    if (tid == 0) { s_qn = 0; s_ovf = 0; }
+    // stage rows y0-4 .. y0+RB+3, columns -4 .. wq+3, BORDER_REFLECT_101 outside the level.
+    // Interior: 16-byte global loads, four in flight per lane before the first LDS write (a load-then-store loop
+    // would serialise on HBM latency); edges (x < 0, x >= 16*floor(w/16)): per-byte reflected loads.
+    const int dpr = pitchL >> 2;
+    const int nch = ((l > 0) || S.aligned16) ? (w >> 4) : 0;     // full 16-byte chunks per row
+    if (nch > 0 && !(ablate & 1)) {
+        const int rpp = nthr / nch;                               // rows staged per pass (nthr >= w/4 > nch)
+        const int my_r = tid / nch, my_c = tid - my_r * nch;
+        if (my_r < rpp) {
+            for (int r0 = my_r; r0 < rowsL; r0 += 4 * rpp) {
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = r0 + k * rpp;
+                    if (r < rowsL) {
+                        const int gy = reflect101(y0 - 4 + r, h);
+                        v[k] = *reinterpret_cast<const uint4*>(img + (int64_t)gy * pitch + 16 * my_c);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = r0 + k * rpp;
+                    if (r < rowsL) {
+                        uint32_t* d = reinterpret_cast<uint32_t*>(s_pix + r * pitchL + 4 + 16 * my_c);
+                        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+                    }
+                }
+            }
+        }
+    }
+    {
+        const int xe0 = nch * 16;                                  // first column not covered by full chunks
+        const int ne = 1 + ((wq + 4 - xe0) >> 2);                  // edge dwords per row: x = -4 and x >= xe0
+        for (int i = tid; i < ((ablate & 1) ? 0 : rowsL * ne); i += nthr) {
+            const int r = i / ne, e = i - r * ne;
+            const int gx = e == 0 ? -4 : xe0 + 4 * (e - 1);
+            const int gy = reflect101(y0 - 4 + r, h);
+            const uint8_t* rowp = img + (int64_t)gy * pitch;
+            const uint32_t v = (uint32_t)rowp[reflect101(gx, w)] | ((uint32_t)rowp[reflect101(gx + 1, w)] << 8) |
+                               ((uint32_t)rowp[reflect101(gx + 2, w)] << 16) | ((uint32_t)rowp[reflect101(gx + 3, w)] << 24);
+            *reinterpret_cast<uint32_t*>(s_pix + r * pitchL + (gx + 4)) = v;
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); FAST is needed on that region + 1 ring
+    const bool level_has_kp = (w > 2 * kEdgeThreshold) && (h > 2 * kEdgeThreshold);
+    const int fx0 = kEdgeThreshold - 1, fx1 = w - kEdgeThreshold;        // inclusive FAST ranges
+    const int fy0 = kEdgeThreshold - 1, fy1 = h - kEdgeThreshold;
+    const int thr = P.fast_threshold;
+
+    const int sb = tid / lpr, li = tid - sb * lpr;       // strip, column group
+    if (sb < nb && !(ablate & 2)) {
+        const int x = li * 4;
+        const int yb = y0 + sb * kBandR;                  // first output row of this strip
+        // per-lane packed masks of the pixels inside the FAST x range (bit 15: px 0/2, bit 31: px 1/3 of a pair)
+        uint32_t xm0 = 0, xm1 = 0;
+        if (level_has_kp) {
+            if (x + 0 >= fx0 && x + 0 <= fx1) xm0 |= 0x00008000u;
+            if (x + 1 >= fx0 && x + 1 <= fx1) xm0 |= 0x80000000u;
+            if (x + 2 >= fx0 && x + 2 <= fx1) xm1 |= 0x00008000u;
+            if (x + 3 >= fx0 && x + 3 <= fx1) xm1 |= 0x80000000u;
+        }
+        const uint32_t T2 = (uint32_t)thr * 0x00010001u;
+        const int o_min = sb == 0 ? -1 : 0, o_max = sb == nb - 1 ? kBandR : kBandR - 1;
+        uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off + x;
+        const int body = w & ~3;   // SymmColumnVec_32s8u (ties to even) covers x < (w & ~3); the scalar tail rounds ties up
+        const bool tie_even_lane = TIE_EVEN && (x < body);
+
+        const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
+        const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
+
+        // 7-row register window; slot = step % 7 (static after unrolling by 7)
+        uint32_t RS[7][4], RC[7], RE[7], RW[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) { RC[u] = RE[u] = RW[u] = 0; RS[u][0] = RS[u][1] = RS[u][2] = RS[u][3] = 0; }
+
+        const uint32_t* lrow = reinterpret_cast<const uint32_t*>(s_pix) + (sb * kBandR) * dpr + li;
+        for (int tb = 0; tb < kStripRows; tb += 7) {
+            uint32_t accw = 0;     // survivors of this group of 7 steps: step u, px j -> bit (j&1 ? 31 : 15) - (j>>1) - 2u
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const int t = tb + u;             // staged row of the strip; level row = yb - 4 + t
+                if (t < kStripRows) {
+                    const uint32_t* rp = lrow + t * dpr;
+                    const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
+                    RC[u] = w1;
+                    RW[u] = __builtin_amdgcn_alignbyte(w1, w0, 1);     // x-3 .. x
+                    RE[u] = __builtin_amdgcn_alignbyte(w2, w1, 3);     // x+3 .. x+6
+                    RS[u][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), KHI,
+                                                      __builtin_amdgcn_udot4(RW[u], KLO, 0u, false), false);
+                    RS[u][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), KHI,
+                                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), KLO, 0u, false), false);
+                    RS[u][2] = __builtin_amdgcn_udot4(RE[u], KHI,
+                                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), KLO, 0u, false), false);
+                    RS[u][3] = __builtin_amdgcn_udot4(w2, KHI, __builtin_amdgcn_udot4(w1, KLO, 0u, false), false);
+
+                    const int o = t - 7;              // strip row whose window [o-3, o+3] is now complete
+                    const int Y = yb + o;
+                    // row o+d of the window lives in slot (u + 4 + d) % 7
+                    const int sC = (u + 4) % 7, sM1 = (u + 3) % 7, sP1 = (u + 5) % 7, sM2 = (u + 2) % 7, sP2 = (u + 6) % 7,
+                              sM3 = (u + 1) % 7, sP3 = u;
+                    if (o >= 0 && o < kBandR && Y < h) {
+                        // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u)
+                        uint32_t outw = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            // operands < 2^24: 24-bit multiplies (v_mad_u32_u24) are full rate, v_mul_lo_u32 is not
+                            uint32_t acc = __umul24(55u, RS[sC][j]) + 32768u;
+                            acc += __umul24(49u, RS[sM1][j] + RS[sP1][j]);
+                            acc += __umul24(34u, RS[sM2][j] + RS[sP2][j]);
+                            acc += __umul24(18u, RS[sM3][j] + RS[sP3][j]);
+                            if (tie_even_lane && (acc & 0x1FFFFu) == 0x10000u) acc -= 0x10000u;   // exact tie, odd quotient -> even
+                            outw |= min(acc >> 16, 255u) << (8 * j);
+                        }
+                        *reinterpret_cast<uint32_t*>(bl + (int64_t)Y * g.pitch) = outw;
+                    }
+                    // the ring rows (o = -1, o = R) are only this strip's job at the block's top / bottom edge;
+                    // inside the block they are ordinary rows of the neighbouring strip
+                    if (o >= o_min && o <= o_max && Y >= fy0 && Y <= fy1) {
+                        // compass reject, two pixels per packed-int16 op: survive iff (N|S)&(E|W) are all darker than
+                        // c - t or all brighter than c + t (every 9-arc holds one pixel of each antipodal compass pair)
+                        uint32_t pass[2];
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) {
+                            const uint32_t sel = pr ? 0x0c030c02u : 0x0c010c00u;
+                            const uint32_t c2 = __builtin_amdgcn_perm(0u, RC[sC], sel);
+                            const uint32_t n2 = __builtin_amdgcn_perm(0u, RC[sM3], sel);
+                            const uint32_t s2 = __builtin_amdgcn_perm(0u, RC[sP3], sel);
+                            const uint32_t e2 = __builtin_amdgcn_perm(0u, RE[sC], sel);
+                            const uint32_t w2p = __builtin_amdgcn_perm(0u, RW[sC], sel);
+                            const uint32_t lo = pk_sub_i16(c2, T2), hi = pk_add_i16(c2, T2);
+                            // sign bit set <=> darker than c - t / brighter than c + t
+                            const uint32_t dk = (pk_sub_i16(n2, lo) | pk_sub_i16(s2, lo)) & (pk_sub_i16(e2, lo) | pk_sub_i16(w2p, lo));
+                            const uint32_t br = (pk_sub_i16(hi, n2) | pk_sub_i16(hi, s2)) & (pk_sub_i16(hi, e2) | pk_sub_i16(hi, w2p));
+                            pass[pr] = (dk | br) & (pr ? xm1 : xm0);
+                        }
+                        accw |= (pass[0] | (pass[1] >> 1)) >> (2 * u);
+                    }
+                }
+            }
+            // append this group's survivors: one LDS atomic per lane, then one store per survivor
+            if (accw) {
+                int base = atomicAdd(&s_qn, __popc(accw));
+                while (accw) {
+                    const int b = 31 - __clz(accw);
+                    accw &= ~(1u << b);
+                    const int hi16 = b >> 4, bb = 15 - (b & 15);
+                    const int u = bb >> 1, px = ((bb & 1) << 1) | hi16;
+                    const uint32_t ro = (uint32_t)(sb * kBandR + tb + u - 6);    // block score row of strip row o = t-7: o+1
+                    if (base < qcap) s_queue[base] = (uint32_t)(x + px) | (ro << 11);
+                    else s_ovf = 1;    // queue full (pathological image): the block is rescored densely below
+                    base++;
+                }
+            }
+        }
+    }
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+
+    uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
+    int* ccnt = cand_cnt + frame * kLevels + l;
+    const int lane = tid & 63;
+    const bool ovf = s_ovf != 0;
+    const int qn = (ovf || (ablate & 4)) ? 0 : s_qn;
+
+    // ---- dense scoring of the queued survivors (all lanes busy); score >= t <=> FAST-9 corner ----
+    for (int i = tid; i < qn; i += nthr) {
+        const uint32_t ent = s_queue[i];
+        const int ex = ent & 0x7FF, ro = (ent >> 11) & 0x1FFF;
+        const int sc = fast_score_pk(s_pix + (ro + 3) * pitchL + (ex + 4), pitchL);
+        s_queue[i] = sc >= thr ? (ent | ((uint32_t)sc << 24)) : 0u;
+    }
+    STAMP(4);
+    __syncthreads();
+    if (!ovf) {
+        // the staged pixels are dead: reuse their LDS as the score map (rows ro = 0 .. RB+1, columns x+1)
+        for (int i = tid; i < ((RB + 2) * sp) >> 2; i += nthr) reinterpret_cast<uint32_t*>(s_map)[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < qn; i += nthr) {
+            const uint32_t ent = s_queue[i];
+            if (ent) s_map[((ent >> 11) & 0x1FFF) * sp + (ent & 0x7FF) + 1] = (uint8_t)(ent >> 24);
+        }
+        __syncthreads();
+    }
+
+    // ---- 3x3 strict-max NMS + border filter. Survivors are compacted into an LDS list (ballot + popcount prefix,
+    //      one LDS atomic per wave), then the workgroup reserves its slice of the global candidate list with ONE
+    //      global atomic and copies the list out: no wave ever waits on an L2 atomic round trip in the loop. ----
+    __shared__ int s_kn, s_gbase;
+    const int map_bytes = (((RB + 2) * sp) + 3) & ~3;
+    uint32_t* s_keep = reinterpret_cast<uint32_t*>(smem + map_bytes);            // spare tail of the staging area
+    const int keep_cap = ovf ? 0 : (rowsL * pitchL - map_bytes) >> 2;
+    if (tid == 0) s_kn = 0;
+    __syncthreads();
+    STAMP(5);
+    const int n_items = (ablate & 8) ? 0 : (ovf ? RB * wq : qn);
+    for (int i0 = 0; i0 < n_items; i0 += nthr) {
+        const int i = i0 + tid;
+        bool keep = false;
+        int X = 0, Y = 0, sc = 0;
+        if (i < n_items) {
+            if (!ovf) {
+                const uint32_t ent = s_queue[i];
+                X = ent & 0x7FF;
+                const int ro = (ent >> 11) & 0x1FFF;
+                sc = ent >> 24;
+                Y = y0 + ro - 1;
+                if (sc > 0 && ro >= 1 && ro <= RB && X >= kEdgeThreshold && X < w - kEdgeThreshold &&
+                    Y >= kEdgeThreshold && Y < h - kEdgeThreshold) {
+                    const uint8_t* s = &s_map[ro * sp + X + 1];
+                    keep = sc > s[-1] && sc > s[1] && sc > s[-sp - 1] && sc > s[-sp] && sc > s[-sp + 1] &&
+                           sc > s[sp - 1] && sc > s[sp] && sc > s[sp + 1];
+                }
+            } else {
+                // slow path for pathological images: score the pixel and, for corners, its 8 neighbours in place
+                const int ro = i / wq + 1;
+                X = i - (ro - 1) * wq;
+                Y = y0 + ro - 1;
+                if (level_has_kp && X >= kEdgeThreshold && X < w - kEdgeThreshold && Y >= kEdgeThreshold &&
+                    Y < h - kEdgeThreshold) {
+                    const uint8_t* c = s_pix + (ro + 3) * pitchL + (X + 4);
+                    sc = fast_score_pk(c, pitchL);
+                    if (sc >= thr) {
+                        keep = true;
+                        for (int dy = -1; dy <= 1 && keep; dy++)
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (dx == 0 && dy == 0) continue;
+                                int ns = fast_score_pk(c + dy * pitchL + dx, pitchL);
+                                if (ns < thr) ns = 0;
+                                if (!(sc > ns)) { keep = false; break; }
+                            }
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_kn, __popcll(mask));
+            base = __shfl(base, leader);
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (keep) {
+                const uint32_t rec = (uint32_t)X | ((uint32_t)Y << 11) | ((uint32_t)sc << 22);
+                if (pos < keep_cap) {
+                    s_keep[pos] = rec;
+                } else {   // LDS list full (or overflow path): straight to the global list
+                    const int gp = atomicAdd(ccnt, 1);
+                    if (gp < g.cand_cap) clist[gp] = rec;
+                    else atomicOr(err, ERRBIT_CAND_OVERFLOW);
+                }
+            }
+        }
+    }
+    STAMP(6);
+    __syncthreads();
+    const int kn = min(s_kn, keep_cap);
+    if (tid == 0 && kn > 0) s_gbase = atomicAdd(ccnt, kn);
+    __syncthreads();
+    if (kn > 0) {
+        const int gb = s_gbase;
+        for (int i = tid; i < kn; i += nthr) {
+            if (gb + i < g.cand_cap) clist[gb + i] = s_keep[i];
+            else atomicOr(err, ERRBIT_CAND_OVERFLOW);
+        }
+    }
+    STAMP(7);
+#undef STAMP
+}
+
+void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("ARIA_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing experiments only
+    // The 8 levels are independent; ARIA_LEVEL_STREAMS=1 forks them onto side streams and joins back on the caller's
+    // stream (useful for small batches where a level's grid does not fill the chip).
+    static hipStream_t side[kLevels] = {};
+    static hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {};
+    static int use_side = -1;
+    if (use_side < 0) {
+        const char* e = getenv("ARIA_LEVEL_STREAMS");
+        use_side = (e && e[0] == '1') ? 1 : 0;   // measured: no gain over back-to-back launches at chunk >= 256; off by default
+        if (use_side) {
+            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+            for (int l = 1; l < kLevels; l++) {
+                hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking);
+                hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming);
+            }
+        }
+    }
+    static unsigned long long* d_stamps = nullptr;
+    static int stamp_level = -2;
+    if (stamp_level == -2) {
+        const char* e = getenv("ARIA_STAMPS");
+        stamp_level = e ? atoi(e) : -1;
+        if (stamp_level >= 0) hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * 65536);
+    }
+    if (use_side) hipEventRecord(ev_fork, st);
+    for (int l = 0; l < kLevels; l++) {
+        const LevelGeom& g = P.lv[l];
+        const BandCfg c = band_cfg(g.w);
+        const int RB = c.nb * kBandR;
+        const dim3 grid((g.h + RB - 1) / RB, n_frames);
+        hipStream_t s = (use_side && l > 0) ? side[l] : st;
+        if (use_side && l > 0) hipStreamWaitEvent(s, ev_fork, 0);
+        if (P.tie_mode == 1)
+            hipLaunchKernelGGL(k_fast_blur_band<1>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr);
+        else
+            hipLaunchKernelGGL(k_fast_blur_band<0>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr);
+        if (use_side && l > 0) { hipEventRecord(ev_join[l], s); hipStreamWaitEvent(st, ev_join[l], 0); }
+        if (l == stamp_level && d_stamps) {   // diagnostic: print mean phase lengths of this launch
+            hipStreamSynchronize(s);
+            const size_t nblk = (size_t)grid.x * grid.y;
+            std::vector<unsigned long long> hs(nblk * 8);
+            hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+            double ph[7] = {0};
+            for (size_t b = 0; b < nblk; b++) for (int k = 0; k < 7; k++) ph[k] += (double)(hs[b * 8 + k + 1] - hs[b * 8 + k]);
+            fprintf(stderr, "[stamps L%d] blocks %zu ticks(100MHz): stage %.0f main %.0f barrier %.0f score %.0f map %.0f nms %.0f out %.0f\n",
+                    l, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, ph[4] / nblk, ph[5] / nblk, ph[6] / nblk);
+        }
+    }
+}
+
+}  // namespace aria

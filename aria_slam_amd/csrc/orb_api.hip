@@ -88,7 +88,7 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
     ARIA_HIP(hipMalloc(&h->D.err, sizeof(int)));
     ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
-    const size_t img_bytes = (size_t)align_up(h->max_w, 4) * h->max_h;
+    const size_t img_bytes = (size_t)align_up(h->max_w, 16) * h->max_h;
     ARIA_HIP(hipMalloc(&h->d_img, img_bytes));
     ARIA_HIP(hipHostMalloc(&h->h_img, img_bytes));
     ARIA_HIP(hipMalloc(&h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
@@ -120,10 +120,10 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     if (!image || stride < width) return ARIA_E_INVALID;
     int rc = ensure_plan(h, width, height);
     if (rc != ARIA_OK) return rc;
-    const int pitch = align_up(width, 4);
+    const int pitch = align_up(width, 16);
     for (int y = 0; y < height; y++) std::memcpy(h->h_img + (size_t)y * pitch, image + (size_t)y * stride, (size_t)width);
     ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, (size_t)pitch * height, hipMemcpyHostToDevice, h->stream));
-    FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1};
+    FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1, (pitch % 16 == 0 && ((int64_t)pitch * height) % 16 == 0) ? 1 : 0};
     h->last_src = S;
     h->have_last = true;
     launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof);
@@ -294,9 +294,10 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
     int rc = ensure_plan(h, width, height);
     if (rc != ARIA_OK) return rc;
     const int aligned4 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
+    const int aligned16 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
     for (int f0 = 0; f0 < n_frames; f0 += h->max_batch) {
         const int nf = std::min(h->max_batch, n_frames - f0);
-        FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4};
+        FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4, aligned16};
         if (f0 == 0) { h->last_src = S; h->have_last = true; }
         launch_extract_chunk(h->plan, S, h->D, nf, d_keypoints + (int64_t)f0 * kp_cap,
                              d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream, &h->prof);

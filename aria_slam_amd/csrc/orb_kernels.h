@@ -16,6 +16,7 @@ struct FrameSrc {
     int64_t frame_stride;   // bytes between frames
     int row_stride;         // bytes between rows
     int aligned4;           // base, frame_stride and row_stride all multiples of 4 -> dword loads allowed
+    int aligned16;          // ... all multiples of 16 -> 16-byte loads allowed
 };
 
 // Per-chunk device scratch owned by the extractor handle (HBM layout: DESIGN.md "Data layout").
@@ -43,10 +44,15 @@ struct Profiler {
     double ms[STAGE_COUNT] = {0, 0, 0, 0};
     int64_t launches[STAGE_COUNT] = {0, 0, 0, 0};
     int64_t frames = 0;
+    int launches_per_pass[STAGE_COUNT] = {kLevels - 1, 1, 1, 1};
     hipEvent_t get();
     void collect();                       // caller has synchronised the stream
     void release();
 };
+
+// band implementation of the FAST+NMS+blur stage (fast_blur_band.hip): 8 launches, one per level
+void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st);
+int fast_blur_impl();   // 1 = band (default), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
 
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,

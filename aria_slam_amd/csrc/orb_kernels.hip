@@ -17,8 +17,10 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
+#include "orb_device.h"
 #include "orb_kernels.h"
 
 namespace aria {
@@ -31,27 +33,16 @@ __device__ const signed char kPattern31[1024] = {
 // computation in tests/test_host_logic.py)
 #define ARIA_UMAX_LIST {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3}
 
-__device__ __forceinline__ const uint8_t* raw_level_ptr(const Plan& P, const FrameSrc& S, const uint8_t* raw,
-                                                        int frame, int l, int& pitch) {
-    if (l == 0) {
-        pitch = S.row_stride;
-        return S.img + (int64_t)frame * S.frame_stride;
-    }
-    pitch = P.lv[l].pitch;
-    return raw + (int64_t)frame * P.raw_frame_bytes + P.lv[l].raw_off;
-}
-
-__device__ __forceinline__ int reflect101(int i, int n) {
-    // BORDER_REFLECT_101; inputs here never lie more than one period outside, clamp guards tiny levels
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * n - 2 - i;
-    return min(max(i, 0), n - 1);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // a6.1  resize.cpp resize_bitExact<uchar, interpolationLinear>: H = c0*p[o] + c1*p[o+1] (exact, 8 frac bits),
 //       out = (cy0*H0 + cy1*H1 + 32768) >> 16. One thread = 4 adjacent output pixels = one dword store.
 // ------------------------------------------------------------------------------------------------------
+// Two bytes p[o], p[o+1] out of a 12-byte window (w0,w1,w2) that starts at byte `base`; e = o - base in [0, 7].
+__device__ __forceinline__ uint32_t window_pair(uint32_t w0, uint32_t w1, uint32_t w2, int e) {
+    const uint32_t lo = e < 4 ? w0 : w1, hi = e < 4 ? w1 : w2;
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)e);    // uses e & 3
+}
+
 __global__ __launch_bounds__(256) void k_resize(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ tab, int l) {
     const LevelGeom g = P.lv[l];
@@ -65,21 +56,50 @@ __global__ __launch_bounds__(256) void k_resize(Plan P, FrameSrc S, uint8_t* __r
     const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
     const uint32_t ty = tab[g.ytab + dy];
     const int oy = ty & 0xFFFF;
-    const uint32_t cy1 = ty >> 16, cy0 = 256u - cy1;
+    const int cy1 = (int)(ty >> 16);
     const uint8_t* r0 = src + (int64_t)oy * spitch;
     const uint8_t* r1 = src + (int64_t)min(oy + 1, sh - 1) * spitch;
+    const int dx0 = gx * 4;
     uint32_t outw = 0;
+    if (dx0 < g.w) {
+        uint32_t tx[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dx = gx * 4 + i;
-        if (dx < g.w) {
-            const uint32_t tx = tab[g.xtab + dx];
-            const int ox = tx & 0xFFFF, ox1 = min(ox + 1, sw - 1);
-            const uint32_t cx1 = tx >> 16, cx0 = 256u - cx1;
-            const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
-            const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
-            const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
-            outw |= min(v, 255u) << (8 * i);
+        for (int i = 0; i < 4; i++) tx[i] = tab[g.xtab + min(dx0 + i, g.w - 1)];
+        const int base = (int)(tx[0] & 0xFFFF) & ~3;
+        // dword path: 3 aligned dwords per source row cover the <= 8 source bytes four outputs need. Only the last
+        // threads of a row of an unpadded, unaligned caller image take the byte path.
+        const bool fast = (l > 1 || S.aligned4) && (base + 12 <= spitch);
+        if (fast) {
+            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(r0 + base);
+            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(r1 + base);
+            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
+            const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int ox = tx[i] & 0xFFFF, cx1 = (int)(tx[i] >> 16);
+                const int e = ox - base;
+                const uint32_t pa = window_pair(a0, a1, a2, e), pb = window_pair(b0, b1, b2, e);
+                const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
+                // c0*p0 + c1*p1 with c0 = 256 - c1  ==  256*p0 + c1*(p1 - p0)   (exact, same integers)
+                const int h0 = (p00 << 8) + cx1 * (p01 - p00);
+                const int h1 = (p10 << 8) + cx1 * (p11 - p10);
+                const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
+                outw |= min(v, 255u) << (8 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int dx = dx0 + i;
+                if (dx < g.w) {
+                    const int ox = tx[i] & 0xFFFF, ox1 = min(ox + 1, sw - 1);
+                    const uint32_t cx1 = tx[i] >> 16, cx0 = 256u - cx1;
+                    const uint32_t cyy1 = (uint32_t)cy1, cyy0 = 256u - cyy1;
+                    const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
+                    const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+                    const uint32_t v = (cyy0 * h0 + cyy1 * h1 + 32768u) >> 16;
+                    outw |= min(v, 255u) << (8 * i);
+                }
+            }
         }
     }
     uint8_t* dst = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
@@ -443,10 +463,16 @@ __device__ __forceinline__ void det_sincos(double x, double& s, double& c) {
     c = (qd == 0) ? cs : (qd == 1) ? -sn : (qd == 2) ? -cs : sn;
 }
 
+// Full-wave integer sum on the DPP crossbar (no LDS traffic): quad swaps, half-row and row mirrors give every lane its
+// 16-lane row total; row_bcast:15 / row_bcast:31 chain the four rows; lane 63 holds the wave total.
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
@@ -536,6 +562,15 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
+int fast_blur_impl() {
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("ARIA_FAST_BLUR_IMPL");
+        impl = (e && e[0] == 't') ? 0 : 1;
+    }
+    return impl;
+}
+
 hipEvent_t Profiler::get() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -547,7 +582,7 @@ void Profiler::collect() {
         for (int s = 0; s < STAGE_COUNT; s++) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, se.ev[s], se.ev[s + 1]) == hipSuccess) ms[s] += t;
-            launches[s] += (s == STAGE_RESIZE) ? (kLevels - 1) : 1;
+            launches[s] += launches_per_pass[s];
         }
         frames += se.n_frames;
         for (int s = 0; s <= STAGE_COUNT; s++) pool.push_back(se.ev[s]);
@@ -581,8 +616,14 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, P, S, D.raw, D.tab, l);
     }
     if (pr) hipEventRecord(se.ev[1], st);
-    hipLaunchKernelGGL(k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur, D.cand,
-                       D.cand_cnt, D.err);
+    if (fast_blur_impl() == 1) {
+        if (prof) prof->launches_per_pass[STAGE_FAST_BLUR] = kLevels;
+        launch_fast_blur_band(P, S, D, n_frames, st);
+    } else {
+        if (prof) prof->launches_per_pass[STAGE_FAST_BLUR] = 1;
+        hipLaunchKernelGGL(k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur, D.cand,
+                           D.cand_cnt, D.err);
+    }
     if (pr) hipEventRecord(se.ev[2], st);
     hipLaunchKernelGGL(k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel,
                        D.sel_cnt, D.err);

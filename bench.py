@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--chunk", type=int, default=256, help="frames per internal extractor pass")
+    ap.add_argument("--chunk", type=int, default=1024, help="frames per internal extractor pass")
     ap.add_argument("--ratio", type=float, default=0.75)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3 runs: extract (and optionally match) a resident batch a few times."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--match", action="store_true")
+    a = ap.parse_args()
+    import torch
+    import aria_slam_amd as A
+    dev = torch.device("cuda", 0)
+    B = 2 * a.pairs
+    host = torch.empty((B, a.height, a.width), dtype=torch.uint8)
+    A.synth_sequence(1, a.pairs, a.width, a.height, out=host.numpy())
+    images = host.to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ext = A.OrbHipExtractor(max_features=a.features, stream=stream, max_width=a.width, max_height=a.height, max_batch=a.chunk)
+    mat = A.HipMatcher(stream=stream)
+    cap = ext.kp_capacity()
+    kps = torch.empty((B, cap, 24), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+    matches = torch.empty((B, cap, 12), dtype=torch.uint8, device=dev)
+    nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+    for _ in range(a.iters):
+        ext.extract_batch_device(images, B, a.width, a.height, kps, desc, counts, cap)
+        if a.match:
+            mat.match_batch_device(desc.data_ptr() + cap * 32, counts.data_ptr() + 4, desc, counts, B - 1, cap * 32, 0.75,
+                                   matches.data_ptr() + cap * 12, nm.data_ptr() + 4, cap)
+    torch.cuda.synchronize()
+    ext.check()
+    mat.sync()
+    print("ok", int(counts.sum().item()))
+
+
+if __name__ == "__main__":
+    main()
