@@ -24,7 +24,7 @@ EXPORTS = [
     "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_extract", "aria_orb_extract_async",
     "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream",
     "aria_orb_set_profiling", "aria_orb_get_profile", "aria_matcher_set_profiling", "aria_matcher_get_profile",
-    "aria_orb_level_info", "aria_orb_resize_table", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
+    "aria_orb_level_info", "aria_orb_resize_table", "aria_orb_pyramid_bands", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
     "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
     "aria_matcher_knn2", "aria_matcher_match_batch_device", "aria_matcher_match_db_device",
     "aria_matcher_stream", "aria_matcher_sync", "aria_synth_frame_pair", "aria_synth_sequence",
@@ -155,6 +155,18 @@ def resize_table(width, height, level, axis):
     if n < 0:
         raise AriaError(n, "aria_orb_resize_table")
     return (buf[:n] & 0xFFFF).astype(np.int32), (buf[:n] >> 16).astype(np.int32)
+
+
+def pyramid_bands(width, height):
+    """(bands[nb, 8, 4] = {comp_lo, comp_n, own_lo, own_n}, band_rows, lds_bytes) of the fused pyramid kernel."""
+    buf = np.zeros(300 * 32, np.int32)
+    bh, lds = C.c_int(), C.c_int()
+    L = load_library()
+    L.aria_orb_pyramid_bands.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    n = L.aria_orb_pyramid_bands(width, height, buf.ctypes.data, len(buf), C.byref(bh), C.byref(lds))
+    if n < 0:
+        raise AriaError(n, "aria_orb_pyramid_bands")
+    return buf[:n].reshape(-1, 8, 4).copy(), bh.value, lds.value
 
 
 def algorithmic_bytes(width, height, n_keypoints):

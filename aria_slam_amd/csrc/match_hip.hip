@@ -23,6 +23,10 @@ using namespace aria;
 namespace {
 
 constexpr int kMatchTile = 256;
+#ifndef ARIA_KNN_SCALAR
+#define ARIA_KNN_SCALAR 1
+#endif
+constexpr bool kUseScalarTrain = ARIA_KNN_SCALAR != 0;
 
 template <int MODE>   // 0: store the two keys per query; 1: count queries passing the double-precision ratio test
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed,
@@ -42,6 +46,37 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
     uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
     if (qi < nq) { qa = qp[2 * qi]; qb = qp[2 * qi + 1]; }
     uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    if (kUseScalarTrain) {
+        // The train descriptor is the same for every lane: read it through the scalar data cache (s_load_dwordx8 into
+        // SGPRs) and feed it to the VALU as scalar operands -- no LDS staging, no barriers, no ds_read issue slots.
+        // Scalar loads return out of order, so the only wait is lgkmcnt(0): fetch the NEXT four descriptors, do the
+        // VALU work of the CURRENT four (~90 instructions) under that latency, then swap.
+        constexpr int U = 4;
+        uint4 ca[U], cb[U], na[U], nb[U];
+        const int last = nt - 1;
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int jj = min(u, last); ca[u] = tp[2 * jj]; cb[u] = tp[2 * jj + 1]; }
+        for (int j = 0; j < nt; j += U) {
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int jj = min(j + U + u, last); na[u] = tp[2 * jj]; nb[u] = tp[2 * jj + 1]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int d = __popc(qa.x ^ ca[u].x);
+                d += __popc(qa.y ^ ca[u].y);
+                d += __popc(qa.z ^ ca[u].z);
+                d += __popc(qa.w ^ ca[u].w);
+                d += __popc(qb.x ^ cb[u].x);
+                d += __popc(qb.y ^ cb[u].y);
+                d += __popc(qb.z ^ cb[u].z);
+                d += __popc(qb.w ^ cb[u].w);
+                const uint32_t key = (j + u < nt) ? (((uint32_t)d << 16) | (uint32_t)(j + u)) : 0xFFFFFFFFu;
+                k1 = min(k1, max(k0, key));
+                k0 = min(k0, key);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
+        }
+    } else
     for (int t0 = 0; t0 < nt; t0 += kMatchTile) {
         __syncthreads();
         if (t0 + tid < nt) {

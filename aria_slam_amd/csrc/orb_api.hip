@@ -31,6 +31,7 @@ struct aria_orb_s {
     Plan plan{};            // plan of the most recent (width, height)
     bool plan_valid = false;
     std::vector<uint32_t> tab_host;
+    std::vector<int> bands_host;
     DeviceScratch D{};
     int kp_cap = 0;         // rows of the internal single-frame output buffers
 
@@ -56,7 +57,7 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 void free_scratch(aria_orb_s* h) {
     hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand); hipFree(h->D.cand_cnt);
-    hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.err);
+    hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.pyr_bands); hipFree(h->D.err);
     hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_count);
     if (h->h_img) hipHostFree(h->h_img);
     if (h->h_kps) hipHostFree(h->h_kps);
@@ -86,6 +87,8 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->D.sel, sizeof(uint2) * (size_t)mp.sel_frame_entries * B));
     ARIA_HIP(hipMalloc(&h->D.sel_cnt, sizeof(int) * kLevels * B));
     ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
+    h->bands_host.assign((size_t)((h->max_h + 7) / 8) * kLevels * 4 + 64, 0);
+    ARIA_HIP(hipMalloc(&h->D.pyr_bands, sizeof(int) * h->bands_host.size()));
     ARIA_HIP(hipMalloc(&h->D.err, sizeof(int)));
     ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
     const size_t img_bytes = (size_t)align_up(h->max_w, 16) * h->max_h;
@@ -112,6 +115,10 @@ int ensure_plan(aria_orb_s* h, int w, int ht) {
     if (used > 0)
         ARIA_HIP(hipMemcpyAsync(h->D.tab, h->tab_host.data(), sizeof(uint32_t) * (size_t)used, hipMemcpyHostToDevice,
                                 h->stream));
+    const int nb_ints = build_pyramid_bands(&h->plan, h->tab_host.data(), h->bands_host.data(), (int)h->bands_host.size());
+    if (nb_ints < 0) return ARIA_E_INVALID;
+    ARIA_HIP(hipMemcpyAsync(h->D.pyr_bands, h->bands_host.data(), sizeof(int) * (size_t)nb_ints, hipMemcpyHostToDevice,
+                            h->stream));
     h->plan_valid = true;
     return ARIA_OK;
 }
@@ -378,6 +385,20 @@ int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* hos
     else { src = h->D.raw + g.raw_off; spitch = (size_t)g.pitch; }
     ARIA_HIP(hipMemcpy2D(host_out, (size_t)g.w, src, spitch, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost));
     return ARIA_OK;
+}
+
+int aria_orb_pyramid_bands(int width, int height, int* out, int cap, int* band_rows, int* lds_bytes) {
+    if (!out) return ARIA_E_INVALID;
+    Plan p;
+    std::vector<uint32_t> tab((size_t)plan_tab_entries(width, height) + 64);
+    int used = 0;
+    int rc = build_plan(width, height, 1000, 0, 1, &p, tab.data(), (int)tab.size(), &used);
+    if (rc != ARIA_OK) return rc;
+    const int n = build_pyramid_bands(&p, tab.data(), out, cap);
+    if (n < 0) return ARIA_E_OUTPUT_TOO_SMALL;
+    if (band_rows) *band_rows = p.pyr_bh;
+    if (lds_bytes) *lds_bytes = p.pyr_lds_bytes;
+    return n;
 }
 
 int aria_orb_algorithmic_bytes(int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused) {

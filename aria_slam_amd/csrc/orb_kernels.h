@@ -28,6 +28,7 @@ struct DeviceScratch {
     uint2* sel;          // [max_batch][sel_frame_entries]  (x | y<<16, harris bits), canonical order per level
     int* sel_cnt;        // [max_batch][8]
     uint32_t* tab;       // resize coefficient tables (ofs | c1 << 16)
+    int* pyr_bands;      // [pyr_nbands][8][4] row ranges of the fused pyramid kernel
     int* err;            // deferred error bits
 };
 

@@ -43,67 +43,306 @@ __device__ __forceinline__ uint32_t window_pair(uint32_t w0, uint32_t w1, uint32
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)e);    // uses e & 3
 }
 
+constexpr int kResizeRows = 8;   // output rows per thread
+
+// One thread = 4 adjacent output pixels x 8 output rows. The level's x table and the block's slice of the y table
+// are staged in LDS with one coalesced round trip; after that the only global accesses are the source rows
+// (3 aligned dwords per source row, 4 rows = 24 loads in flight per lane) and the dword stores.
 __global__ __launch_bounds__(256) void k_resize(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ tab, int l) {
+    extern __shared__ uint32_t s_rt[];        // [w] x table, then [kResizeRows * (rc1 - rc0 + 1)] y slice
     const LevelGeom g = P.lv[l];
     const int frame = blockIdx.y;
     const int groups = g.pitch >> 2;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= groups * g.h) return;
-    const int dy = gid / groups, gx = gid - dy * groups;
+    const int nrc = (g.h + kResizeRows - 1) / kResizeRows;
+    const int total = groups * nrc;
+    const int gid0 = blockIdx.x * 256;
+    const int rc_first = gid0 / groups, rc_last = min(gid0 + 255, total - 1) / groups;
+    uint32_t* s_yt = s_rt + g.w;
+    for (int i = threadIdx.x; i < g.w; i += 256) s_rt[i] = tab[g.xtab + i];
+    {
+        const int y0 = rc_first * kResizeRows, ny = min((rc_last + 1) * kResizeRows, g.h) - y0;
+        for (int i = threadIdx.x; i < ny; i += 256) s_yt[i] = tab[g.ytab + y0 + i];
+    }
+    __syncthreads();
+    const int gid = gid0 + threadIdx.x;
+    if (gid >= total) return;
+    const int rc = gid / groups, gx = gid - rc * groups;
     int spitch;
     const uint8_t* src = raw_level_ptr(P, S, raw, frame, l - 1, spitch);
     const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
-    const uint32_t ty = tab[g.ytab + dy];
-    const int oy = ty & 0xFFFF;
-    const int cy1 = (int)(ty >> 16);
-    const uint8_t* r0 = src + (int64_t)oy * spitch;
-    const uint8_t* r1 = src + (int64_t)min(oy + 1, sh - 1) * spitch;
+    uint8_t* dst = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off + gx * 4;
     const int dx0 = gx * 4;
-    uint32_t outw = 0;
-    if (dx0 < g.w) {
-        uint32_t tx[4];
+    const int dy0 = rc * kResizeRows;
+    const uint32_t* yt = s_yt + (rc - rc_first) * kResizeRows;
+    if (dx0 >= g.w) {   // row padding up to the 16-byte pitch: keep it deterministic
+        for (int r = 0; r < kResizeRows && dy0 + r < g.h; r++) *reinterpret_cast<uint32_t*>(dst + (int64_t)(dy0 + r) * g.pitch) = 0u;
+        return;
+    }
+    uint32_t tx[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) tx[i] = tab[g.xtab + min(dx0 + i, g.w - 1)];
-        const int base = (int)(tx[0] & 0xFFFF) & ~3;
-        // dword path: 3 aligned dwords per source row cover the <= 8 source bytes four outputs need. Only the last
-        // threads of a row of an unpadded, unaligned caller image take the byte path.
-        const bool fast = (l > 1 || S.aligned4) && (base + 12 <= spitch);
-        if (fast) {
-            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(r0 + base);
-            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(r1 + base);
-            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
-            const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
+    for (int i = 0; i < 4; i++) tx[i] = s_rt[min(dx0 + i, g.w - 1)];
+    const int base = (int)(tx[0] & 0xFFFF) & ~3;
+    int e[4], cx1[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int ox = tx[i] & 0xFFFF, cx1 = (int)(tx[i] >> 16);
-                const int e = ox - base;
-                const uint32_t pa = window_pair(a0, a1, a2, e), pb = window_pair(b0, b1, b2, e);
-                const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
-                // c0*p0 + c1*p1 with c0 = 256 - c1  ==  256*p0 + c1*(p1 - p0)   (exact, same integers)
-                const int h0 = (p00 << 8) + cx1 * (p01 - p00);
-                const int h1 = (p10 << 8) + cx1 * (p11 - p10);
-                const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
-                outw |= min(v, 255u) << (8 * i);
+    for (int i = 0; i < 4; i++) { e[i] = (int)(tx[i] & 0xFFFF) - base; cx1[i] = (int)(tx[i] >> 16); }
+    // dword path: 3 aligned dwords per source row cover the <= 9 source bytes four outputs need (scale ~1.2). Only
+    // the last threads of a row of an unpadded / unaligned caller image take the byte path.
+    const bool fast = (l > 1 || S.aligned4) && (base + 12 <= spitch) && e[3] <= 7;
+    if (fast) {
+#pragma unroll 4
+        for (int r = 0; r < kResizeRows; r++) {
+            const int dy = dy0 + r;
+            if (dy < g.h) {
+                const uint32_t ty = yt[r];
+                const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
+                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (int64_t)oy * spitch + base);
+                const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (int64_t)min(oy + 1, sh - 1) * spitch + base);
+                const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
+                const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
+                uint32_t outw = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t pa = window_pair(a0, a1, a2, e[i]), pb = window_pair(b0, b1, b2, e[i]);
+                    const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
+                    // c0*p0 + c1*p1 with c0 = 256 - c1  ==  256*p0 + c1*(p1 - p0)   (exact, same integers)
+                    const int h0 = (p00 << 8) + cx1[i] * (p01 - p00);
+                    const int h1 = (p10 << 8) + cx1[i] * (p11 - p10);
+                    const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
+                    outw |= min(v, 255u) << (8 * i);
+                }
+                *reinterpret_cast<uint32_t*>(dst + (int64_t)dy * g.pitch) = outw;
             }
-        } else {
+        }
+    } else {
+        for (int r = 0; r < kResizeRows; r++) {
+            const int dy = dy0 + r;
+            if (dy >= g.h) break;
+            const uint32_t ty = yt[r];
+            const int oy = ty & 0xFFFF;
+            const uint32_t cyy1 = ty >> 16, cyy0 = 256u - cyy1;
+            const uint8_t* r0 = src + (int64_t)oy * spitch;
+            const uint8_t* r1 = src + (int64_t)min(oy + 1, sh - 1) * spitch;
+            uint32_t outw = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int dx = dx0 + i;
-                if (dx < g.w) {
+                if (dx0 + i < g.w) {
                     const int ox = tx[i] & 0xFFFF, ox1 = min(ox + 1, sw - 1);
-                    const uint32_t cx1 = tx[i] >> 16, cx0 = 256u - cx1;
-                    const uint32_t cyy1 = (uint32_t)cy1, cyy0 = 256u - cyy1;
-                    const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
-                    const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+                    const uint32_t c1 = tx[i] >> 16, c0 = 256u - c1;
+                    const uint32_t h0 = c0 * r0[ox] + c1 * r0[ox1];
+                    const uint32_t h1 = c0 * r1[ox] + c1 * r1[ox1];
                     const uint32_t v = (cyy0 * h0 + cyy1 * h1 + 32768u) >> 16;
                     outw |= min(v, 255u) << (8 * i);
                 }
             }
+            *reinterpret_cast<uint32_t*>(dst + (int64_t)dy * g.pitch) = outw;
         }
     }
-    uint8_t* dst = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
-    *reinterpret_cast<uint32_t*>(dst + (int64_t)dy * g.pitch + gx * 4) = outw;
+}
+
+// a6.1, LDS-staged form: a workgroup produces kResizeBand output rows of level l. The source rows it needs
+// (~1.2 * band + 2) are staged with coalesced 16-byte loads, 4 in flight per lane, so the texture path sees wide
+// contiguous requests instead of three overlapping dword gathers per lane; the x table and the band's y slice ride
+// along in LDS; the bilinear taps are then dword windows read from LDS.
+constexpr int kResizeBand = 16;
+
+__global__ __launch_bounds__(256) void k_resize_lds(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
+                                                    const uint32_t* __restrict__ tab, int l) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_rs[];
+    const LevelGeom g = P.lv[l];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.y;
+    const int dy0 = blockIdx.x * kResizeBand, ndy = min(kResizeBand, g.h - dy0);
+    int spitch;
+    const uint8_t* src = raw_level_ptr(P, S, raw, frame, l - 1, spitch);
+    const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
+    const int lp = (sw + 15) / 16 * 16 + 16;                     // LDS pitch of a staged source row (+16: window slack)
+    const int max_rows = (kResizeBand * 13) / 10 + 4;            // rows a band can need at scale ~1.2
+    uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_rs + max_rows * lp);
+    uint32_t* s_yt = s_xt + g.w;
+    const uint32_t* ytg = tab + g.ytab + dy0;
+    const int oy_lo = (int)(ytg[0] & 0xFFFF);
+    const int oy_hi = min((int)(ytg[ndy - 1] & 0xFFFF) + 1, sh - 1);
+    const int nrows = min(oy_hi - oy_lo + 1, max_rows);
+    for (int i = tid; i < g.w; i += 256) s_xt[i] = tab[g.xtab + i];
+    if (tid < ndy) s_yt[tid] = ytg[tid];
+    const bool a16 = (l > 1) || S.aligned16;
+    const int nch = a16 ? (sw >> 4) : 0;
+    if (nch > 0 && nch <= 256) {
+        const int rpp = 256 / nch;
+        const int my_r = tid / nch, my_c = tid - my_r * nch;
+        if (my_r < rpp) {
+            for (int r0 = my_r; r0 < nrows; r0 += 4 * rpp) {
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = r0 + k * rpp;
+                    if (r < nrows) v[k] = *reinterpret_cast<const uint4*>(src + (int64_t)(oy_lo + r) * spitch + 16 * my_c);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = r0 + k * rpp;
+                    if (r < nrows) *reinterpret_cast<uint4*>(smem_rs + r * lp + 16 * my_c) = v[k];
+                }
+            }
+        }
+    }
+    {
+        const int xe0 = (nch > 0 && nch <= 256) ? nch * 16 : 0;
+        const int ne = sw - xe0;
+        for (int i = tid; i < nrows * ne; i += 256) {
+            const int r = i / ne, c = xe0 + (i - r * ne);
+            smem_rs[r * lp + c] = src[(int64_t)(oy_lo + r) * spitch + c];
+        }
+    }
+    __syncthreads();
+
+    uint8_t* dg = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
+    const int groups = g.pitch >> 2;
+    const int items = ndy * groups;
+    const float inv_groups = 1.0f / (float)groups;
+    for (int it = tid; it < items; it += 256) {
+        int r = (int)((float)it * inv_groups);
+        if (r * groups > it) r--;
+        else if ((r + 1) * groups <= it) r++;
+        const int gx = it - r * groups;
+        const int dx0 = gx * 4;
+        uint32_t outw = 0;
+        if (dx0 < g.w) {
+            const uint32_t ty = s_yt[r];
+            const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
+            uint32_t tx[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) tx[i] = s_xt[min(dx0 + i, g.w - 1)];
+            const int base = (int)(tx[0] & 0xFFFF) & ~3;
+            const int ra = min(oy - oy_lo, nrows - 1), rb = min(min(oy + 1, sh - 1) - oy_lo, nrows - 1);
+            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(smem_rs + ra * lp + base);
+            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(smem_rs + rb * lp + base);
+            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
+            const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = min((int)(tx[i] & 0xFFFF) - base, 7), cx1 = (int)(tx[i] >> 16);
+                const uint32_t pa = window_pair(a0, a1, a2, e), pb = window_pair(b0, b1, b2, e);
+                const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
+                const int h0 = (p00 << 8) + cx1 * (p01 - p00);      // == (256-cx1)*p00 + cx1*p01
+                const int h1 = (p10 << 8) + cx1 * (p11 - p10);
+                const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
+                outw |= min(v, 255u) << (8 * i);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(dg + (int64_t)(dy0 + r) * g.pitch + dx0) = outw;
+    }
+}
+
+// a6.1 fused: one workgroup builds levels 1..7 for a band of level-0 rows entirely in LDS: the level-0 band, the x
+// tables and each level's y-table slice are staged once, level l is resized from the level l-1 rows the same workgroup
+// just produced, and every row it owns goes to HBM exactly once. Nothing is re-read from HBM between levels, no item
+// waits on a global load, and the 7 dependent launches collapse into one.
+__global__ __launch_bounds__(256) void k_pyramid(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
+                                                 const uint32_t* __restrict__ tab, const int* __restrict__ bands) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_pyr[];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.y;
+    const int* B = bands + (int)blockIdx.x * kLevels * 4;
+    uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_pyr + P.pyr_xtab_off);
+    uint32_t* s_yt = reinterpret_cast<uint32_t*>(smem_pyr + P.pyr_ytab_off);
+    const int xt_lo = P.lv[1].xtab;
+
+    // ---- stage: x tables, y slice of level 1, level-0 rows [comp_lo, comp_lo + comp_n) ----
+    for (int i = tid; i < P.pyr_xtab_n; i += 256) s_xt[i] = tab[xt_lo + i];
+    {
+        const int clo = B[4 + 0], cn = B[4 + 1];
+        if (tid < cn) s_yt[tid] = tab[P.lv[1].ytab + clo + tid];
+    }
+    {
+        const int lo0 = B[0], n0 = B[1], w0 = P.lv[0].w, p0 = P.pyr_p0;
+        const uint8_t* img = S.img + (int64_t)frame * S.frame_stride;
+        uint8_t* d0 = smem_pyr + P.pyr_off[0];
+        const int nch = S.aligned16 ? (w0 >> 4) : 0;
+        if (nch > 0) {
+            const int rpp = 256 / nch > 0 ? 256 / nch : 1;
+            const int my_r = tid / nch, my_c = tid - my_r * nch;
+            if (my_r < rpp && nch <= 256) {
+                for (int r0 = my_r; r0 < n0; r0 += 4 * rpp) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int r = r0 + k * rpp;
+                        if (r < n0) v[k] = *reinterpret_cast<const uint4*>(img + (int64_t)(lo0 + r) * S.row_stride + 16 * my_c);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int r = r0 + k * rpp;
+                        if (r < n0) *reinterpret_cast<uint4*>(d0 + r * p0 + 16 * my_c) = v[k];
+                    }
+                }
+            }
+        }
+        const int xe0 = (nch > 0 && nch <= 256) ? nch * 16 : 0;     // columns not covered by the 16-byte chunks
+        const int ne = w0 - xe0;
+        for (int i = tid; i < n0 * ne; i += 256) {
+            const int r = i / ne, c = xe0 + (i - r * ne);
+            d0[r * p0 + c] = img[(int64_t)(lo0 + r) * S.row_stride + c];
+        }
+    }
+    __syncthreads();
+
+    for (int l = 1; l < kLevels; l++) {
+        const LevelGeom g = P.lv[l];
+        const int comp_lo = B[l * 4 + 0], comp_n = B[l * 4 + 1], own_n = B[l * 4 + 3];
+        const int src_lo = B[(l - 1) * 4 + 0];
+        const int sh = P.lv[l - 1].h;
+        const int spitch = l == 1 ? P.pyr_p0 : P.lv[l - 1].pitch;
+        const uint8_t* src = smem_pyr + P.pyr_off[l - 1];      // LDS row 0 is level row src_lo
+        uint8_t* dl = smem_pyr + P.pyr_off[l];
+        uint8_t* dg = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
+        const uint32_t* xt = s_xt + (g.xtab - xt_lo);
+        const int groups = g.pitch >> 2;
+        const int items = comp_n * groups;
+        const float inv_groups = 1.0f / (float)groups;
+        for (int it = tid; it < items; it += 256) {
+            int r = (int)((float)it * inv_groups);
+            if (r * groups > it) r--;
+            else if ((r + 1) * groups <= it) r++;
+            const int gx = it - r * groups;
+            const int dy = comp_lo + r;
+            const int dx0 = gx * 4;
+            uint32_t outw = 0;
+            if (dx0 < g.w) {
+                const uint32_t ty = s_yt[r];
+                const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
+                uint32_t tx[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) tx[i] = xt[min(dx0 + i, g.w - 1)];
+                const int base = (int)(tx[0] & 0xFFFF) & ~3;
+                // 3 aligned dwords per source row cover the <= 9 source bytes four outputs need (scale ~1.2); a window
+                // may run past the row's end into the next LDS row: those bytes only ever meet weight 0
+                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (oy - src_lo) * spitch + base);
+                const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (min(oy + 1, sh - 1) - src_lo) * spitch + base);
+                const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
+                const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int e = min((int)(tx[i] & 0xFFFF) - base, 7), cx1 = (int)(tx[i] >> 16);
+                    const uint32_t pa = window_pair(a0, a1, a2, e), pb = window_pair(b0, b1, b2, e);
+                    const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
+                    const int h0 = (p00 << 8) + cx1 * (p01 - p00);      // == (256-cx1)*p00 + cx1*p01
+                    const int h1 = (p10 << 8) + cx1 * (p11 - p10);
+                    const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
+                    outw |= min(v, 255u) << (8 * i);
+                }
+            }
+            *reinterpret_cast<uint32_t*>(dl + r * g.pitch + dx0) = outw;
+            if (r < own_n) *reinterpret_cast<uint32_t*>(dg + (int64_t)dy * g.pitch + dx0) = outw;
+        }
+        __syncthreads();
+        if (l + 1 < kLevels) {       // y slice of the next level (the slice just used is dead after the barrier)
+            const int clo = B[(l + 1) * 4 + 0], cn = B[(l + 1) * 4 + 1];
+            if (tid < cn) s_yt[tid] = tab[P.lv[l + 1].ytab + clo + tid];
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -602,6 +841,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     if (!lds_attr_set) {   // k_select may need more than the default 64 KB of dynamic LDS for very large quotas
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(unsigned long long) * kSortCapMax));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         lds_attr_set = true;
     }
     const bool pr = prof && prof->enabled;
@@ -610,10 +850,34 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     if (pr) for (int s = 0; s <= STAGE_COUNT; s++) se.ev[s] = prof->get();
     hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
     if (pr) hipEventRecord(se.ev[0], st);
-    for (int l = 1; l < kLevels; l++) {
-        const int items = (P.lv[l].pitch >> 2) * P.lv[l].h;
-        dim3 grid((items + 255) / 256, n_frames);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, P, S, D.raw, D.tab, l);
+    static int pyr_impl = -1;   // 0 = one k_resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
+                                // measured slower at 640x480: the top-down halo makes small bands recompute too much)
+    if (pyr_impl < 0) { const char* e = getenv("ARIA_PYRAMID_IMPL"); pyr_impl = (e && e[0] == 'f') ? 1 : 0; }
+    if (pyr_impl == 1 && P.pyr_lds_bytes <= 150 * 1024) {
+        if (prof) prof->launches_per_pass[STAGE_RESIZE] = 1;
+        hipLaunchKernelGGL(k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S, D.raw, D.tab,
+                           D.pyr_bands);
+    } else {
+        if (prof) prof->launches_per_pass[STAGE_RESIZE] = kLevels - 1;
+        static int rs_impl = -1;    // 1 = LDS-staged bands (default), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)
+        if (rs_impl < 0) { const char* e = getenv("ARIA_RESIZE_IMPL"); rs_impl = (e && e[0] == 'd') ? 0 : 1; }
+        for (int l = 1; l < kLevels; l++) {
+            if (rs_impl == 1) {
+                const int lp = (P.lv[l - 1].w + 15) / 16 * 16 + 16;
+                const size_t lds = (size_t)((kResizeBand * 13) / 10 + 4) * lp + sizeof(uint32_t) * ((size_t)P.lv[l].w + kResizeBand) + 16;
+                if (lds <= 64 * 1024) {
+                    hipLaunchKernelGGL(k_resize_lds, dim3((P.lv[l].h + kResizeBand - 1) / kResizeBand, n_frames), dim3(256), lds, st,
+                                       P, S, D.raw, D.tab, l);
+                    continue;
+                }
+            }
+            const int items = (P.lv[l].pitch >> 2) * ((P.lv[l].h + kResizeRows - 1) / kResizeRows);
+            dim3 grid((items + 255) / 256, n_frames);
+            // LDS: the level's x table + the y entries of the row-chunks a block can touch (256 items span <= 256/groups + 2 chunks)
+            const int groups = P.lv[l].pitch >> 2;
+            const size_t lds = sizeof(uint32_t) * ((size_t)P.lv[l].w + (size_t)kResizeRows * (256 / groups + 2));
+            hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
+        }
     }
     if (pr) hipEventRecord(se.ev[1], st);
     if (fast_blur_impl() == 1) {

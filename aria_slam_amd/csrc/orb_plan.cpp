@@ -129,4 +129,77 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
     return ARIA_OK;
 }
 
+// Row ownership for the fused pyramid kernel. Level l+1 row dy is a blend of level l rows oy(dy), oy(dy)+1.
+//   own_0     = the band's level-0 rows
+//   own_{l+1} = { dy : oy_{l+1}(dy) in own_l }          (contiguous because oy is monotone; partitions level l+1)
+//   comp_l    = own_l plus the extra trailing rows deeper levels of this band read (one more per level at most)
+static int pyramid_bands_for(Plan* P, const uint32_t* tab, int bh, int* out, int out_capacity) {
+    const int xt_lo = P->lv[1].xtab, xt_hi = P->lv[kLevels - 1].xtab + P->lv[kLevels - 1].w;
+    const int p0 = (P->lv[0].w + 15) / 16 * 16;
+    const int nb = (P->lv[0].h + bh - 1) / bh;
+    if (nb * kLevels * 4 > out_capacity) return -1;
+    int cap[kLevels] = {0};
+    for (int b = 0; b < nb; b++) {
+        int own_lo[kLevels], own_hi[kLevels], comp_hi[kLevels];
+        own_lo[0] = b * bh;
+        own_hi[0] = std::min(P->lv[0].h, (b + 1) * bh);
+        for (int l = 1; l < kLevels; l++) {
+            const uint32_t* yt = tab + P->lv[l].ytab;
+            int lo = 0, hi = 0;
+            while (lo < P->lv[l].h && (int)(yt[lo] & 0xFFFF) < own_lo[l - 1]) lo++;   // first dy with oy >= own_lo[l-1]
+            hi = lo;
+            while (hi < P->lv[l].h && (int)(yt[hi] & 0xFFFF) < own_hi[l - 1]) hi++;   // first dy with oy >= own_hi[l-1]
+            own_lo[l] = lo;
+            own_hi[l] = hi;
+        }
+        comp_hi[kLevels - 1] = own_hi[kLevels - 1];
+        for (int l = kLevels - 2; l >= 0; l--) {
+            int need = own_hi[l];
+            if (comp_hi[l + 1] > own_lo[l + 1]) {
+                const uint32_t* yt = tab + P->lv[l + 1].ytab;
+                const int oy_last = (int)(yt[comp_hi[l + 1] - 1] & 0xFFFF);
+                need = std::max(need, std::min(P->lv[l].h, oy_last + 2));
+            }
+            comp_hi[l] = need;
+        }
+        for (int l = 0; l < kLevels; l++) {
+            int* o = out + (b * kLevels + l) * 4;
+            o[0] = own_lo[l];
+            o[1] = comp_hi[l] - own_lo[l];
+            o[2] = own_lo[l];
+            o[3] = own_hi[l] - own_lo[l];
+            cap[l] = std::max(cap[l], o[1]);
+            if (o[1] > kPyrYSlice) return -1;
+        }
+    }
+    int off = 0;
+    P->pyr_p0 = p0;
+    for (int l = 0; l < kLevels; l++) {
+        P->pyr_off[l] = off;
+        off += (cap[l] + 1) * (l == 0 ? p0 : P->lv[l].pitch);   // +1 row of slack: dword windows may run past a row's end
+    }
+    P->pyr_xtab_off = off;
+    P->pyr_xtab_n = xt_hi - xt_lo;
+    off += 4 * (xt_hi - xt_lo);
+    P->pyr_ytab_off = off;
+    off += 4 * kPyrYSlice;
+    P->pyr_bh = bh;
+    P->pyr_nbands = nb;
+    P->pyr_lds_bytes = off + 64;
+    return nb * kLevels * 4;
+}
+
+int build_pyramid_bands(Plan* P, const uint32_t* tab, int* out, int out_capacity) {
+    // Largest band height (multiple of 8) whose exact LDS footprint lets 3, else 2, else 1 workgroups share a CU.
+    // Note the halo: a band's deepest level needs one extra source row per level above it, amplified by 1.2 per
+    // level, so small bands recompute a lot; measured slower than per-level launches at 640x480.
+    const int budgets[3] = {53 * 1024, 80 * 1024, 150 * 1024};
+    for (int bi = 0; bi < 3; bi++)
+        for (int bh = 64; bh >= 8; bh -= 8) {
+            const int n = pyramid_bands_for(P, tab, bh, out, out_capacity);
+            if (n > 0 && P->pyr_lds_bytes <= budgets[bi]) return n;
+        }
+    return pyramid_bands_for(P, tab, 8, out, out_capacity);
+}
+
 }  // namespace aria

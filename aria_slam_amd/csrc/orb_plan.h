@@ -23,6 +23,7 @@ constexpr int kPatchH = kTileH + 2 * kHalo;  // 40
 constexpr int kSortCapMin = 4096;    // LDS bitonic sort capacity of the per-(frame,level) selection kernel (entries of 8 B)
 constexpr int kSortCapMax = 16384;   // 128 KB of the CU's 160 KB LDS
 constexpr int kSelSlack = 64;    // extra output slots per level for ties at the Harris cut
+constexpr int kPyrYSlice = 96;   // max rows a pyramid band computes per level
 constexpr int kMaxDim = 2047;    // candidate packing: x:11 | y:11 | score:8
 
 struct LevelGeom {
@@ -52,6 +53,13 @@ struct Plan {
     int tie_mode;
     int fast_threshold;
     int sort_cap;             // power of two in [kSortCapMin, kSortCapMax]
+    // fused pyramid kernel: a workgroup owns pyr_bh level-0 rows and builds the matching rows of levels 1..7 in LDS
+    int pyr_bh, pyr_nbands, pyr_lds_bytes;
+    int pyr_off[kLevels];     // LDS byte offset of the level-l row buffer (level 0: the staged source band)
+    int pyr_xtab_off;         // LDS byte offset of the copied x tables (uint32, indexed by lv[l].xtab - lv[1].xtab)
+    int pyr_ytab_off;         // LDS byte offset of the per-level y-table slice (uint32, kPyrYSlice entries)
+    int pyr_p0;               // LDS pitch of the staged level-0 band
+    int pyr_xtab_n;           // entries of the x-table copy
     int _pad2;
     int64_t raw_frame_bytes;
     int64_t blur_frame_bytes;
@@ -62,5 +70,8 @@ struct Plan {
 int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie_mode, Plan* plan,
                uint32_t* tab, int tab_capacity, int* tab_used);
 int64_t plan_tab_entries(int width, int height);
+// Per band and level: {comp_lo, comp_n, own_lo, own_n} = rows the band computes / rows it also writes to HBM.
+// Returns the number of ints written (pyr_nbands * kLevels * 4). Fills plan->pyr_*.
+int build_pyramid_bands(Plan* plan, const uint32_t* tab, int* out, int out_capacity);
 
 }  // namespace aria

@@ -130,6 +130,9 @@ int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms /*[4]*/, int6
  * aria_orb_resize_table returns the number of entries written (or a negative status). */
 int aria_orb_level_info(int max_features, int width, int height, int level, int* lw, int* lh, int* quota, float* scale);
 int aria_orb_resize_table(int width, int height, int level, int axis, uint32_t* out, int cap);
+/* Row schedule of the fused pyramid kernel (host-only, for tests): per band of level-0 rows and per level, four ints
+ * {first row computed, rows computed, first row owned, rows owned}. Returns the number of ints written. */
+int aria_orb_pyramid_bands(int width, int height, int* out, int cap, int* band_rows, int* lds_bytes);
 /* Algorithmic bytes of one frame: b_extract = 5P - p0 - p7 + 56N, b_fused = 2P + 56N. */
 int aria_orb_algorithmic_bytes(int width, int height, int n_keypoints, int64_t* b_extract, int64_t* b_fused);
 /* Copies level `level` (raw or blurred) of frame 0 of the most recent call to host memory (lw*lh bytes, packed). */

@@ -63,6 +63,32 @@ def test_resize_tables_match_oracle(aria, oracle, w, h):
             assert np.array_equal(ofs, oo) and np.array_equal(c1, oc)
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (752, 480), (1408, 1408), (333, 251), (2047, 1024), (100, 100), (64, 2047)])
+def test_fused_pyramid_row_schedule(aria, oracle, w, h):
+    """Every level row is owned by exactly one band, and every row a band reads was computed by that band."""
+    from aria_slam_amd import _lib
+    bands, bh, lds = _lib.pyramid_bands(w, h)
+    sizes = oracle.level_sizes(oracle.default_params(), w, h)
+    assert bh >= 8
+    if w <= 1408:
+        assert lds <= 150 * 1024      # wider images fall back to one resize launch per level
+    nb = len(bands)
+    for l in range(8):
+        lw, lh = sizes[l]
+        owned = np.zeros(lh, int)
+        for b in range(nb):
+            clo, cn, olo, on = bands[b, l]
+            assert clo == olo and cn >= on >= 0 and 0 <= clo and clo + cn <= lh
+            owned[olo:olo + on] += 1
+            if l >= 1 and cn > 0:
+                oy, _ = aria.resize_table(w, h, l, 1)
+                src_lo, src_n = bands[b, l - 1, 0], bands[b, l - 1, 1]
+                need_lo = oy[clo:clo + cn].min()
+                need_hi = min(oy[clo:clo + cn].max() + 1, sizes[l - 1][1] - 1)
+                assert src_lo <= need_lo and need_hi < src_lo + src_n, (l, b)
+        assert np.all(owned == 1), "level %d rows not owned exactly once" % l
+
+
 def test_algorithmic_bytes_match_baseline_md(aria):
     # BASELINE.md section 3 table
     assert aria.algorithmic_bytes(640, 480, 2000) == (4533474, 2013064)
