@@ -69,6 +69,31 @@ def build_library(force=False):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so; this library links the system one. If both copies end up in
+    one process (library loaded first, torch imported later) the second runtime finds no device. So when a torch
+    installation is present, map its copy first: the loader then satisfies our NEEDED libamdhip64.so.7 from it and a
+    later `import torch` reuses it too. Without torch nothing happens and the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if not spec or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Load the HIP library. Never falls back to anything else: a missing library is an error."""
     global _lib
@@ -77,6 +102,7 @@ def load_library():
     if not os.path.exists(_SO):
         raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _SO)
+    _preload_torch_hip_runtime()
     L = C.CDLL(_SO)
     L.aria_status_string.restype = C.c_char_p
     L.aria_last_hip_error.restype = C.c_char_p

@@ -28,6 +28,13 @@ constexpr int kMatchTile = 256;
 #endif
 constexpr bool kUseScalarTrain = ARIA_KNN_SCALAR != 0;
 
+// v_bcnt_u32_b32 dst, src, acc: popcount(src) + acc in one VALU instruction
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 template <int MODE>   // 0: store the two keys per query; 1: count queries passing the double-precision ratio test
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed,
                                               const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed,
@@ -61,17 +68,22 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
             for (int u = 0; u < U; u++) { const int jj = min(j + U + u, last); na[u] = tp[2 * jj]; nb[u] = tp[2 * jj + 1]; }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                int d = __popc(qa.x ^ ca[u].x);
-                d += __popc(qa.y ^ ca[u].y);
-                d += __popc(qa.z ^ ca[u].z);
-                d += __popc(qa.w ^ ca[u].w);
-                d += __popc(qb.x ^ cb[u].x);
-                d += __popc(qb.y ^ cb[u].y);
-                d += __popc(qb.z ^ cb[u].z);
-                d += __popc(qb.w ^ cb[u].w);
-                const uint32_t key = (j + u < nt) ? (((uint32_t)d << 16) | (uint32_t)(j + u)) : 0xFFFFFFFFu;
-                k1 = min(k1, max(k0, key));
-                k0 = min(k0, key);
+                // 8 x (v_xor, v_bcnt accumulate): the popcount adds into its own accumulator operand, no adder tree
+                uint32_t d = 0;
+                d = bcnt_acc(qa.x ^ ca[u].x, d);
+                d = bcnt_acc(qa.y ^ ca[u].y, d);
+                d = bcnt_acc(qa.z ^ ca[u].z, d);
+                d = bcnt_acc(qa.w ^ ca[u].w, d);
+                d = bcnt_acc(qb.x ^ cb[u].x, d);
+                d = bcnt_acc(qb.y ^ cb[u].y, d);
+                d = bcnt_acc(qb.z ^ cb[u].z, d);
+                d = bcnt_acc(qb.w ^ cb[u].w, d);
+                const uint32_t key = (j + u < nt) ? ((d << 16) | (uint32_t)(j + u)) : 0xFFFFFFFFu;
+                // most candidates lose against every lane's current runner-up: one compare + a uniform branch
+                if (__any(key < k1)) {
+                    k1 = min(k1, max(k0, key));
+                    k0 = min(k0, key);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) { ca[u] = na[u]; cb[u] = nb[u]; }

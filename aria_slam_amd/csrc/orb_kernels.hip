@@ -25,7 +25,7 @@
 
 namespace aria {
 
-__device__ const signed char kPattern31[1024] = {
+__device__ __attribute__((aligned(16))) const signed char kPattern31[1024] = {
 #include "orb_pattern_31.inc"
 };
 
@@ -714,14 +714,22 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// The rotated pattern never leaves [-18, 18]^2 (|x|,|y| <= 13*sqrt(2)), so a 37-row x 44-byte window of the blurred
+// level (dword-aligned start) holds every sample of a keypoint.
+constexpr int kDescR = 18;
+constexpr int kDescRows = 2 * kDescR + 1;   // 37
+constexpr int kDescPitch = 44;              // 11 dwords >= 37 + 3 bytes of alignment slack
+
 __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint2* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescRows * kDescPitch];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wv;
     const int* cnt = sel_cnt + frame * kLevels;
     int l = 0, base = 0, total = 0;
 #pragma unroll
@@ -743,6 +751,22 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint
     const uint2 sv = sel[(int64_t)frame * P.sel_frame_entries + slot];
     const int x = sv.x & 0xFFFF, y = sv.x >> 16;
 
+    // pattern rows of this lane (independent of the keypoint): issue early
+    int pat[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) pat[w] = *reinterpret_cast<const int*>(&kPattern31[(w * 64 + lane) * 4]);
+
+    // ---- prefetch the blurred 37 x 44 window into LDS (overlaps the intensity-centroid gathers below) ----
+    const uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
+    const int xs = (x - kDescR) & ~3;                      // dword-aligned first column (keypoints are >= 31 px inside)
+    uint32_t pv[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int d = lane + 64 * k;                        // dword index in the window, row-major, 11 per row
+        const int r = d / 11, c = d - r * 11;
+        pv[k] = (d < kDescRows * 11) ? *reinterpret_cast<const uint32_t*>(bl + (int64_t)(y - kDescR + r) * g.pitch + xs + 4 * c) : 0u;
+    }
+
     // ---- orb.cpp ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (integer, order-free) ----
     int pitch;
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
@@ -761,26 +785,34 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint
             m01 += sgn * v * val;
         }
     }
+    // park the window in LDS while the moments reduce
+    uint32_t* sp = reinterpret_cast<uint32_t*>(s_patch[wv]);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int d = lane + 64 * k;
+        if (d < kDescRows * 11) sp[d] = pv[k];
+    }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- orb.cpp computeOrbDescriptors (WTA_K 2) on the blurred level ----
+    // ---- orb.cpp computeOrbDescriptors (WTA_K 2) on the blurred level, samples served from the LDS window ----
     float ang = angle;
     ang *= (float)(3.1415926535897932384626433832795 / 180.f);
     double sd, cd;
     det_sincos((double)ang, sd, cd);
     const float a = (float)cd, b = (float)sd;
-    const uint8_t* bc = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off + (int64_t)y * g.pitch + x;
+    const uint8_t* bc = s_patch[wv] + kDescR * kDescPitch + (x - xs);     // window address of the keypoint centre
+    __builtin_amdgcn_wave_barrier();
     unsigned long long mine = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const signed char* pt = &kPattern31[(w * 64 + lane) * 4];
-        const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+        const float px0 = (float)(signed char)(pat[w] & 0xFF), py0 = (float)(signed char)((pat[w] >> 8) & 0xFF);
+        const float px1 = (float)(signed char)((pat[w] >> 16) & 0xFF), py1 = (float)(signed char)((pat[w] >> 24) & 0xFF);
         const float fx0 = px0 * a - py0 * b, fy0 = px0 * b + py0 * a;
         const float fx1 = px1 * a - py1 * b, fy1 = px1 * b + py1 * a;
-        const int t0 = bc[(int)rintf(fy0) * g.pitch + (int)rintf(fx0)];
-        const int t1 = bc[(int)rintf(fy1) * g.pitch + (int)rintf(fx1)];
+        const int t0 = bc[(int)rintf(fy0) * kDescPitch + (int)rintf(fx0)];
+        const int t1 = bc[(int)rintf(fy1) * kDescPitch + (int)rintf(fx1)];
         const unsigned long long m = __ballot(t0 < t1);
         if (lane == w) mine = m;
     }
