@@ -403,7 +403,8 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
 #undef STAMP
 }
 
-void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st) {
+void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                           Profiler* prof) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -443,10 +444,13 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
         const dim3 grid((g.h + RB - 1) / RB, n_frames);
         hipStream_t s = (use_side && l > 0) ? side[l] : st;
         if (use_side && l > 0) hipStreamWaitEvent(s, ev_fork, 0);
+        unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
         if (P.tie_mode == 1)
-            hipLaunchKernelGGL(k_fast_blur_band<1>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr);
+            ARIA_LAUNCH(prof, k_fast_blur_band<1>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand,
+                        D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp);
         else
-            hipLaunchKernelGGL(k_fast_blur_band<0>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr);
+            ARIA_LAUNCH(prof, k_fast_blur_band<0>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand,
+                        D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp);
         if (use_side && l > 0) { hipEventRecord(ev_join[l], s); hipStreamWaitEvent(st, ev_join[l], 0); }
         if (l == stamp_level && d_stamps) {   // diagnostic: print mean phase lengths of this launch
             hipStreamSynchronize(s);

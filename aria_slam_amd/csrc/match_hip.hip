@@ -9,6 +9,7 @@
 // are staged through LDS in tiles of 256 and read as wave-uniform (broadcast) ds_read_b128; the running top-2
 // is kept as two packed keys (distance << 16 | train index) so ties resolve to the lower index for free.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <climits>
@@ -205,7 +206,7 @@ struct aria_matcher_s {
     int* h_idx = nullptr;           // pinned
     // optional stage timing (HIP events on the launch stream)
     bool prof_enabled = false;
-    struct Ev { hipEvent_t e[3]; int pairs; };
+    struct Ev { hipEvent_t e[4]; int pairs; };
     std::vector<Ev> prof_pending;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[2] = {0, 0};
@@ -221,11 +222,11 @@ struct aria_matcher_s {
         for (Ev& v : prof_pending) {
             for (int s = 0; s < 2; s++) {
                 float t = 0.f;
-                if (hipEventElapsedTime(&t, v.e[s], v.e[s + 1]) == hipSuccess) prof_ms[s] += t;
+                if (hipEventElapsedTime(&t, v.e[2 * s], v.e[2 * s + 1]) == hipSuccess) prof_ms[s] += t;
                 prof_launches[s] += 1;
             }
             prof_pairs += v.pairs;
-            for (int s = 0; s < 3; s++) prof_pool.push_back(v.e[s]);
+            for (int s = 0; s < 4; s++) prof_pool.push_back(v.e[s]);
         }
         prof_pending.clear();
     }
@@ -421,15 +422,24 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
     ARIA_HIP(hipSetDevice(m->device));
     int rc = ensure_keys(m, (size_t)n_pairs * (size_t)maxq);
     if (rc != ARIA_OK) return rc;
+    // profiling: drain the stream, then bracket each kernel with an event pair (see orb_kernels.h Profiler)
     aria_matcher_s::Ev ev;
     ev.pairs = n_pairs;
-    if (m->prof_enabled) { for (int s = 0; s < 3; s++) ev.e[s] = m->prof_get(); hipEventRecord(ev.e[0], m->stream); }
+    if (m->prof_enabled) {
+        for (int s = 0; s < 4; s++) ev.e[s] = m->prof_get();
+        hipStreamSynchronize(m->stream);
+        hipEventRecord(ev.e[0], m->stream);
+    }
     hipLaunchKernelGGL(k_knn2<0>, dim3((unsigned)((maxq + 255) / 256), n_pairs), dim3(256), 0, m->stream, d_query, d_nq,
                        0, d_train, d_nt, 0, desc_stride, desc_stride, m->d_keys, (int)maxq, 0.0, nullptr);
-    if (m->prof_enabled) hipEventRecord(ev.e[1], m->stream);
+    if (m->prof_enabled) {
+        hipEventRecord(ev.e[1], m->stream);
+        hipStreamSynchronize(m->stream);
+        hipEventRecord(ev.e[2], m->stream);
+    }
     hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
                        d_matches, d_nmatches, match_cap, m->d_err);
-    if (m->prof_enabled) { hipEventRecord(ev.e[2], m->stream); m->prof_pending.push_back(ev); }
+    if (m->prof_enabled) { hipEventRecord(ev.e[3], m->stream); m->prof_pending.push_back(ev); }
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

@@ -1,6 +1,7 @@
 // Kernel-launch interface between the C-ABI host code (orb_api.hip) and the kernels (orb_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <vector>
@@ -32,27 +33,39 @@ struct DeviceScratch {
     int* err;            // deferred error bits
 };
 
-// Optional per-stage timing: HIP events recorded on the launch stream around each stage of a chunk.
+// Optional per-stage timing (bench.py's roofline figure). HIP event pairs bracket each stage on the launch stream;
+// the stream is drained before the start event so the bracket holds exactly that stage's kernels (event markers
+// placed between back-to-back dependent launches do not bracket kernel execution precisely on this stack: their
+// intervals overlap and sum to more than the wall clock). Costs one stream sync per stage per pass (< 2 % at
+// 1024-frame passes); off by default.
 enum { STAGE_RESIZE = 0, STAGE_FAST_BLUR = 1, STAGE_SELECT = 2, STAGE_DESCRIBE = 3, STAGE_COUNT = 4 };
-struct StageEvents {
-    hipEvent_t ev[STAGE_COUNT + 1];   // boundaries: ev[s] .. ev[s+1] brackets stage s
-    int n_frames;
-};
+struct LaunchEvents { hipEvent_t start, stop; int stage; int launches; };
 struct Profiler {
     bool enabled = false;
-    std::vector<StageEvents> pending;     // recorded, not yet read
+    std::vector<LaunchEvents> pending;    // recorded, not yet read
     std::vector<hipEvent_t> pool;         // recycled events
     double ms[STAGE_COUNT] = {0, 0, 0, 0};
     int64_t launches[STAGE_COUNT] = {0, 0, 0, 0};
     int64_t frames = 0;
-    int launches_per_pass[STAGE_COUNT] = {kLevels - 1, 1, 1, 1};
+    LaunchEvents cur{};
     hipEvent_t get();
-    void collect();                       // caller has synchronised the stream
+    void begin(int stage, hipStream_t st);   // drain the stream, record the start event
+    void count() { cur.launches++; }
+    void end(hipStream_t st);                // record the stop event
+    void collect();                          // caller has synchronised the stream
     void release();
 };
 
+// Launch `kernel`; counted into the open stage when profiling is on.
+#define ARIA_LAUNCH(prof, kernel, grid, block, lds, st, ...)                       \
+    do {                                                                           \
+        if ((prof) && (prof)->enabled) (prof)->count();                            \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);             \
+    } while (0)
+
 // band implementation of the FAST+NMS+blur stage (fast_blur_band.hip): 8 launches, one per level
-void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st);
+void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                           Profiler* prof);
 int fast_blur_impl();   // 1 = band (default), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
 
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,

@@ -724,12 +724,17 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint
                                                   const uint8_t* __restrict__ blur, const uint2* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
-                                                  int* __restrict__ err) {
+                                                  int* __restrict__ err, int n_frames, int blocks_per_frame) {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescRows * kDescPitch];
-    const int frame = blockIdx.y;
+    // XCD-aware block -> (frame, slot) map. Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share
+    // one; speed only, never correctness), and each XCD has its own L2. Give every XCD whole frames, so a frame's raw
+    // and blurred patches are fetched into ONE L2 instead of up to eight (PMC: 9.6 MB -> see profiles/ per frame).
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int frame = (j / blocks_per_frame) * 8 + xcd;
+    if (frame >= n_frames) return;
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wv;
+    const int slot = (j % blocks_per_frame) * 4 + wv;
     const int* cnt = sel_cnt + frame * kLevels;
     int l = 0, base = 0, total = 0;
 #pragma unroll
@@ -848,15 +853,24 @@ hipEvent_t Profiler::get() {
     hipEventCreate(&e);
     return e;
 }
+void Profiler::begin(int stage, hipStream_t st) {
+    if (!enabled) return;
+    cur = LaunchEvents{get(), get(), stage, 0};
+    hipStreamSynchronize(st);
+    hipEventRecord(cur.start, st);
+}
+void Profiler::end(hipStream_t st) {
+    if (!enabled) return;
+    hipEventRecord(cur.stop, st);
+    pending.push_back(cur);
+}
 void Profiler::collect() {
-    for (StageEvents& se : pending) {
-        for (int s = 0; s < STAGE_COUNT; s++) {
-            float t = 0.f;
-            if (hipEventElapsedTime(&t, se.ev[s], se.ev[s + 1]) == hipSuccess) ms[s] += t;
-            launches[s] += launches_per_pass[s];
-        }
-        frames += se.n_frames;
-        for (int s = 0; s <= STAGE_COUNT; s++) pool.push_back(se.ev[s]);
+    for (LaunchEvents& le : pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, le.start, le.stop) == hipSuccess) ms[le.stage] += t;
+        launches[le.stage] += le.launches;
+        pool.push_back(le.start);
+        pool.push_back(le.stop);
     }
     pending.clear();
 }
@@ -870,27 +884,24 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
                           Profiler* prof) {
     static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // k_select may need more than the default 64 KB of dynamic LDS for very large quotas
+    if (!lds_attr_set) {   // kernels that may need more than the default 64 KB of dynamic LDS
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(unsigned long long) * kSortCapMax));
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         lds_attr_set = true;
     }
-    const bool pr = prof && prof->enabled;
-    StageEvents se;
-    se.n_frames = n_frames;
-    if (pr) for (int s = 0; s <= STAGE_COUNT; s++) se.ev[s] = prof->get();
+    if (prof && prof->enabled) prof->frames += n_frames;
     hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
-    if (pr) hipEventRecord(se.ev[0], st);
-    static int pyr_impl = -1;   // 0 = one k_resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
+
+    // ---- a6.1 pyramid ----
+    if (prof) prof->begin(STAGE_RESIZE, st);
+    static int pyr_impl = -1;   // 0 = one resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
                                 // measured slower at 640x480: the top-down halo makes small bands recompute too much)
     if (pyr_impl < 0) { const char* e = getenv("ARIA_PYRAMID_IMPL"); pyr_impl = (e && e[0] == 'f') ? 1 : 0; }
     if (pyr_impl == 1 && P.pyr_lds_bytes <= 150 * 1024) {
-        if (prof) prof->launches_per_pass[STAGE_RESIZE] = 1;
-        hipLaunchKernelGGL(k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S, D.raw, D.tab,
-                           D.pyr_bands);
+        ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S,
+                    D.raw, D.tab, D.pyr_bands);
     } else {
-        if (prof) prof->launches_per_pass[STAGE_RESIZE] = kLevels - 1;
         static int rs_impl = -1;    // 1 = LDS-staged bands (default), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)
         if (rs_impl < 0) { const char* e = getenv("ARIA_RESIZE_IMPL"); rs_impl = (e && e[0] == 'd') ? 0 : 1; }
         for (int l = 1; l < kLevels; l++) {
@@ -898,8 +909,8 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
                 const int lp = (P.lv[l - 1].w + 15) / 16 * 16 + 16;
                 const size_t lds = (size_t)((kResizeBand * 13) / 10 + 4) * lp + sizeof(uint32_t) * ((size_t)P.lv[l].w + kResizeBand) + 16;
                 if (lds <= 64 * 1024) {
-                    hipLaunchKernelGGL(k_resize_lds, dim3((P.lv[l].h + kResizeBand - 1) / kResizeBand, n_frames), dim3(256), lds, st,
-                                       P, S, D.raw, D.tab, l);
+                    ARIA_LAUNCH(prof, k_resize_lds, dim3((P.lv[l].h + kResizeBand - 1) / kResizeBand, n_frames),
+                                dim3(256), lds, st, P, S, D.raw, D.tab, l);
                     continue;
                 }
             }
@@ -908,25 +919,39 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
             // LDS: the level's x table + the y entries of the row-chunks a block can touch (256 items span <= 256/groups + 2 chunks)
             const int groups = P.lv[l].pitch >> 2;
             const size_t lds = sizeof(uint32_t) * ((size_t)P.lv[l].w + (size_t)kResizeRows * (256 / groups + 2));
-            hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
+            ARIA_LAUNCH(prof, k_resize, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
         }
     }
-    if (pr) hipEventRecord(se.ev[1], st);
+
+    if (prof) prof->end(st);
+
+    // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
+    if (prof) prof->begin(STAGE_FAST_BLUR, st);
     if (fast_blur_impl() == 1) {
-        if (prof) prof->launches_per_pass[STAGE_FAST_BLUR] = kLevels;
-        launch_fast_blur_band(P, S, D, n_frames, st);
+        launch_fast_blur_band(P, S, D, n_frames, st, prof);
     } else {
-        if (prof) prof->launches_per_pass[STAGE_FAST_BLUR] = 1;
-        hipLaunchKernelGGL(k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur, D.cand,
-                           D.cand_cnt, D.err);
+        ARIA_LAUNCH(prof, k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur,
+                    D.cand, D.cand_cnt, D.err);
     }
-    if (pr) hipEventRecord(se.ev[2], st);
-    hipLaunchKernelGGL(k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel,
-                       D.sel_cnt, D.err);
-    if (pr) hipEventRecord(se.ev[3], st);
-    hipLaunchKernelGGL(k_describe, dim3((P.sel_frame_entries + 3) / 4, n_frames), dim3(256), 0, st, P, S, D.raw,
-                       D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err);
-    if (pr) { hipEventRecord(se.ev[4], st); prof->pending.push_back(se); }
+
+    if (prof) prof->end(st);
+
+    // ---- a6.3-a6.5 selection ----
+    if (prof) prof->begin(STAGE_SELECT, st);
+    ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
+                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err);
+
+    if (prof) prof->end(st);
+
+    // ---- a6.6 + a6.8 angle + descriptor ----
+    if (prof) prof->begin(STAGE_DESCRIBE, st);
+    {
+        const int bpf = (P.sel_frame_entries + 3) / 4;
+        const int frames8 = (n_frames + 7) / 8 * 8;
+        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(256), 0, st, P, S, D.raw, D.blur,
+                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf);
+    }
+    if (prof) prof->end(st);
 }
 
 }  // namespace aria

@@ -1,0 +1,53 @@
+// aria::pipeline::FrontEnd -- the front half of SlamPipeline::processFrame over the reference's ports
+// (SURVEY.md 8f row 1). The reference declares SlamPipeline (include/pipeline/SlamPipeline.hpp:29-106) but ships no
+// implementation; its sketch of processFrame (docs/milestones/H12_CLEAN_ARCHITECTURE.md:595-605) is
+//     extractor_->extract(image_data, width, height, frame);
+//     matcher_->match(frame, *prev_frame_, matches);          // query = current, train = previous
+// followed by pose / fusion / mapping stages that are out of scope here. FrontEnd runs exactly those two calls,
+// keeps the previous frame, and hands {frame, matches} to the caller (or a callback) -- so any IFeatureExtractor /
+// IMatcher pair (the HIP adapters, or mocks) can be driven the way SlamPipeline is designed to drive them.
+#pragma once
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "aria_hip/compat.hpp"
+
+namespace aria::pipeline {
+
+struct FrontEndConfig {
+    float ratio_threshold = 0.75f;     // IMatcher default (IMatcher.hpp:23); euroc_eval uses 0.75 too (euroc_eval.cpp:172)
+    // false: query = current, train = previous (SlamPipeline sketch, H12...:601)
+    // true : query = previous, train = current (what the legacy executables do, src/euroc_eval.cpp:168-169)
+    bool legacy_order = false;
+};
+
+struct FrontEndResult {
+    const core::Frame* frame = nullptr;       // the frame just extracted (owned by the FrontEnd until the next call)
+    const core::Frame* previous = nullptr;    // nullptr on the first frame
+    std::vector<core::Match> matches;         // empty on the first frame
+};
+
+class FrontEnd {
+public:
+    FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::MatcherPtr matcher, const FrontEndConfig& cfg = {});
+
+    // image_data: grayscale, row-major, width*height bytes (the extractor port's contract, IFeatureExtractor.hpp:14)
+    const FrontEndResult& processFrame(const std::uint8_t* image_data, int width, int height, double timestamp);
+
+    void setCallback(std::function<void(const FrontEndResult&)> cb) { callback_ = std::move(cb); }
+    std::uint64_t framesProcessed() const { return next_id_; }
+    interfaces::IFeatureExtractor& extractor() { return *extractor_; }
+    interfaces::IMatcher& matcher() { return *matcher_; }
+
+private:
+    interfaces::FeatureExtractorPtr extractor_;
+    interfaces::MatcherPtr matcher_;
+    FrontEndConfig cfg_;
+    std::unique_ptr<core::Frame> cur_, prev_;
+    FrontEndResult result_;
+    std::function<void(const FrontEndResult&)> callback_;
+    std::uint64_t next_id_ = 0;
+};
+
+}  // namespace aria::pipeline

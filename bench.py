@@ -27,6 +27,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def host_cores():
+    """Cores this process may really use: affinity, capped by the cgroup CPU quota and by the GPU box's share of
+    16 per GPU (sched_getaffinity reports all 256 host threads there)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("ARIA_CPU_BASELINE_THREADS", "16"))))
+
+
+def load_traffic(chunk):
+    """HBM bytes per frame of k_fast_blur_band from the committed PMC passes (tools/pmc_traffic.sh), or None."""
+    for name in ("pmc_traffic_%d.json" % chunk, "pmc_traffic_1024.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            k = json.load(open(f))["kernels"].get("k_fast_blur_band")
+            if k:
+                return k["fetch_bytes_per_frame"] + k["write_bytes_per_frame"], name
+    return None, None
+
+
 def cpu_baseline(width, height, nfeatures, budget_s=12.0):
     """Time the CPU oracle (a port of the reference's CPU OpenCV path, oracle/orb_oracle.cpp) on this host:
     frame-parallel, one worker thread per core, each unit = 1 extract + 1 match (same accounting as the GPU)."""
@@ -35,7 +59,7 @@ def cpu_baseline(width, height, nfeatures, budget_s=12.0):
     from oracle import oracle_py as O
     O.build()
     O.lib()
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     p = O.default_params(nfeatures)
     done = [0] * cores
     t_end = time.time() + budget_s
@@ -185,11 +209,14 @@ def main():
         frames_per_launch = prof_frames / max(launches["fast_blur"], 1)
         fb_bytes_per_launch = alg["fast_blur"] * frames_per_launch
         achieved = fb_bytes_per_launch / (fb_ms_per_launch * 1e-3) / 1e9 if fb_ms_per_launch > 0 else 0.0
+        traffic_pf, traffic_src = load_traffic(args.chunk)
         ext_ms = sum(stage_ms[k] for k in ("resize", "fast_blur", "select", "describe"))
         roofline = {
-            "bound": "hbm", "kernel": "k_fast_blur (FAST-9 + NMS + 7x7 Gaussian, fused on one LDS tile)",
+            "bound": "hbm", "kernel": "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level, fused; 8 level launches per pass)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": (int(traffic_pf * frames_per_launch) if traffic_pf and (W, H, NF) == (640, 480, 2000) else None),
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(fb_bytes_per_launch),
             "avg_launch_ms": round(fb_ms_per_launch, 4), "frames_per_launch": frames_per_launch,
             "dominant_stage": dom,

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "aria_hip/FrontEnd.hpp"
 #include "aria_hip/HipMatcher.hpp"
 #include "aria_hip/OrbHipExtractor.hpp"
 #include "aria_orb_hip.h"
@@ -23,8 +24,61 @@ static unsigned long long fnv(const void* p, size_t n, unsigned long long h = 14
     return h;
 }
 
+// Mocks in the spirit of the reference's planned MockExtractor / MockMatcher
+// (docs/milestones/H12_CLEAN_ARCHITECTURE.md:629-645, 1795-1815): no GPU, deterministic outputs.
+struct MockExtractor : interfaces::IFeatureExtractor {
+    int max_features = 3, calls = 0;
+    void extract(const uint8_t* image, int w, int h, core::Frame& f) override {
+        calls++;
+        f.width = w; f.height = h;
+        f.keypoints.assign((size_t)max_features, core::KeyPoint{(float)image[0], 2.f, 31.f, 0.f, 1.f, 0});
+        f.descriptors.assign((size_t)max_features * 32, image[0]);
+    }
+    void setMaxFeatures(int n) override { max_features = n; }
+    int getMaxFeatures() const override { return max_features; }
+};
+struct MockMatcher : interfaces::IMatcher {
+    std::vector<std::pair<unsigned long long, unsigned long long>> calls;   // (query.id, train.id)
+    float last_ratio = -1.f;
+    void match(const core::Frame& q, const core::Frame& t, std::vector<core::Match>& m, float ratio) override {
+        calls.push_back({q.id, t.id});
+        last_ratio = ratio;
+        m.push_back({0, 0, (float)(q.descriptors[0] ^ t.descriptors[0])});
+    }
+};
+
+static int frontend_mock_test() {
+    int ok = 1;
+    for (int legacy = 0; legacy < 2; legacy++) {
+        auto ex = std::make_unique<MockExtractor>();
+        auto mt = std::make_unique<MockMatcher>();
+        MockMatcher* mtp = mt.get();
+        pipeline::FrontEndConfig cfg;
+        cfg.legacy_order = legacy != 0;
+        cfg.ratio_threshold = 0.7f;
+        pipeline::FrontEnd fe(std::move(ex), std::move(mt), cfg);
+        int cb = 0;
+        fe.setCallback([&](const pipeline::FrontEndResult& r) { cb++; ok &= (r.frame != nullptr); });
+        std::vector<uint8_t> img(640 * 480, 128);                       // the prose test's constant-128 image (H12...:1803)
+        const auto& r0 = fe.processFrame(img.data(), 640, 480, 0.0);
+        ok &= r0.matches.empty() && r0.previous == nullptr && r0.frame->id == 0 && r0.frame->numKeypoints() == 3;
+        img[0] = 130;
+        const auto& r1 = fe.processFrame(img.data(), 640, 480, 0.05);
+        ok &= r1.matches.size() == 1 && r1.previous && r1.previous->id == 0 && r1.frame->id == 1 && r1.frame->timestamp == 0.05;
+        ok &= mtp->calls.size() == 1 && mtp->last_ratio == 0.7f;
+        if (legacy) ok &= mtp->calls[0].first == 0 && mtp->calls[0].second == 1;       // prev -> current (euroc_eval.cpp:168)
+        else ok &= mtp->calls[0].first == 1 && mtp->calls[0].second == 0;              // current -> prev (H12...:601)
+        ok &= r1.matches[0].distance == (float)(130 ^ 128);
+        fe.processFrame(img.data(), 640, 480, 0.1);
+        ok &= cb == 3 && fe.framesProcessed() == 3 && mtp->calls.size() == 2;
+    }
+    std::printf("%s frontend_mock\n", ok ? "OK" : "FAIL");
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "gpu";
+    if (mode == "frontend_mock") return frontend_mock_test();
     const int W = 640, H = 480;
     std::vector<uint8_t> a((size_t)W * H), b((size_t)W * H);
     aria_synth_frame_pair(1, W, H, a.data(), b.data());

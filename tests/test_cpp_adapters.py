@@ -24,7 +24,7 @@ def selftest(aria):
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(PKG, "libaria_hip_adapters.so"))):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(PKG, "host", "include"), src, "-o", EXE, "-L" + PKG,
-                               "-laria_hip_adapters", "-laria_orb_hip", "-Wl,-rpath," + PKG])
+                               "-laria_hip_adapters", "-laria_orb_hip", "-lz", "-Wl,-rpath," + PKG])
     return EXE
 
 

@@ -1,0 +1,162 @@
+"""the SlamPipeline front half over the ports (FrontEnd) and the ASL/EuRoC input format
+(CSV + PNG reader, euroc_eval-style driver)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "aria_slam_amd")
+
+
+def _chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+
+def write_png(img, filters="mixed", level=6):
+    """Minimal PNG encoder (8-bit gray HxW or RGB/RGBA HxWxC) that exercises every scanline filter type."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        cur = rows[y]
+        ft = (y % 5) if filters == "mixed" else int(filters)
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - a
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((a + prev) >> 1)
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            f = cur - pred
+        raw.append(ft)
+        raw += (f & 0xFF).astype(np.uint8).tobytes()
+        prev = cur
+    comp = zlib.compress(bytes(raw), level)
+    idat = b"".join(_chunk(b"IDAT", comp[i:i + 8000]) for i in range(0, len(comp), 8000))     # several IDAT chunks
+    return (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+            _chunk(b"tEXt", b"Comment\x00synthetic") + idat + _chunk(b"IEND", b""))
+
+
+@pytest.fixture(scope="module")
+def hostlib(aria):
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host"), "-s"])
+    aria.load_library()
+    L = C.CDLL(os.path.join(PKG, "libaria_hip_adapters.so"))
+    L.aria_asl_decode_png_gray.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.aria_asl_list.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    return L
+
+
+def _decode(L, png):
+    out = np.zeros(2048 * 2048, np.uint8)
+    w, h = C.c_int(), C.c_int()
+    buf = np.frombuffer(png, np.uint8)
+    rc = L.aria_asl_decode_png_gray(buf.ctypes.data, len(png), out.ctypes.data, out.size, C.byref(w), C.byref(h))
+    return rc, (out[:w.value * h.value].reshape(h.value, w.value).copy() if rc == 0 else None)
+
+
+def test_png_decoder_all_filters_and_colour_types(aria, hostlib):
+    a, _ = aria.synth_frame_pair(5, 752, 480)
+    for filt in ("mixed", 0, 1, 2, 3, 4):
+        rc, g = _decode(hostlib, write_png(a, filt))
+        assert rc == 0 and np.array_equal(g, a), filt
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    want = ((rgb[..., 0].astype(int) * 4899 + rgb[..., 1].astype(int) * 9617 + rgb[..., 2].astype(int) * 1868 + 8192) >> 14).astype(np.uint8)
+    rc, g = _decode(hostlib, write_png(rgb))
+    assert rc == 0 and np.array_equal(g, want)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (37, 53, 1), dtype=np.uint8)], 2)
+    rc, g = _decode(hostlib, write_png(rgba))
+    assert rc == 0 and np.array_equal(g, want)
+    ga = np.stack([a[:20, :30], a[20:40, :30]], 2)
+    rc, g = _decode(hostlib, write_png(ga))
+    assert rc == 0 and np.array_equal(g, a[:20, :30])
+    # malformed inputs fail cleanly
+    good = write_png(a[:16, :16])
+    for bad in (good[:20], b"\x00" * 64, good[:-20], good.replace(b"IHDR", b"IHDX")):
+        assert _decode(hostlib, bad)[0] != 0
+
+
+def _make_dataset(aria, root, n_pairs, w=320, h=240, shuffle=True):
+    cam = os.path.join(root, "mav0", "cam0", "data")
+    os.makedirs(cam, exist_ok=True)
+    seq = aria.synth_sequence(40, n_pairs, w, h)
+    t0 = 1403636579763555584
+    rows = []
+    for i in range(len(seq)):
+        ts = t0 + i * 50_000_000                                   # 20 Hz (H07_EUROC_DATASET_AUDIT.md:16)
+        name = "%d.png" % ts
+        open(os.path.join(cam, name), "wb").write(write_png(seq[i]))
+        rows.append("%d,%s" % (ts, name))
+    if shuffle:
+        rows = rows[3:] + rows[:3]                                 # the reader must sort by timestamp
+    with open(os.path.join(root, "mav0", "cam0", "data.csv"), "w") as f:
+        f.write("#timestamp [ns],filename\n" + "\n".join(rows) + "\n\n# trailing comment\n")
+    return seq, t0
+
+
+def test_asl_sequence_listing(aria, hostlib, tmp_path):
+    seq, t0 = _make_dataset(aria, str(tmp_path), 4)
+    ts = np.zeros(64, np.float64)
+    first = C.create_string_buffer(512)
+    n = hostlib.aria_asl_list(str(tmp_path).encode(), ts.ctypes.data, 64, first, 512)
+    assert n == 8
+    assert np.all(np.diff(ts[:n]) > 0) and abs(ts[0] - t0 * 1e-9) < 1e-3 and abs((ts[1] - ts[0]) - 0.05) < 1e-6
+    assert first.value.decode().endswith("%d.png" % t0)
+    assert hostlib.aria_asl_list(os.path.join(str(tmp_path), "mav0").encode(), ts.ctypes.data, 64, first, 512) == 8
+    assert hostlib.aria_asl_list(b"/nonexistent", ts.ctypes.data, 64, first, 512) == -1
+
+
+def test_frontend_over_mock_ports():
+    exe = os.path.join(ROOT, "tests", "cpp", "adapter_selftest")
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host"), "-s"])
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_selftest.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "host", "include"), src, "-o", exe, "-L" + PKG,
+                           "-laria_hip_adapters", "-laria_orb_hip", "-lz", "-Wl,-rpath," + PKG])
+    out = subprocess.run([exe, "frontend_mock"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "OK frontend_mock" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("legacy", [False, True])
+def test_euroc_frontend_driver_on_synthetic_asl(aria, hostlib, tmp_path, legacy):
+    seq, _ = _make_dataset(aria, str(tmp_path), 6)
+    csv = os.path.join(str(tmp_path), "out.csv")
+    exe = os.path.join(PKG, "euroc_frontend")
+    cmd = [exe, str(tmp_path), "800", "--csv", csv] + (["--legacy-order"] if legacy else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l.split(",") for l in open(csv).read().strip().split("\n")[1:]]
+    assert len(rows) == len(seq)
+    e = aria.OrbHipExtractor(max_features=800, max_width=320, max_height=240)
+    m = aria.HipMatcher()
+    try:
+        prev = None
+        for i, img in enumerate(seq):
+            f = e.extract(img)
+            nm = 0
+            if prev is not None:
+                nm = len(m.match(prev, f) if legacy else m.match(f, prev))
+            assert int(rows[i][2]) == len(f["keypoints"]) and int(rows[i][3]) == nm, i
+            prev = f
+    finally:
+        e.close()
+        m.close()
+    assert "mean_matches" in out.stdout

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Reduce the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh to HBM bytes per frame per kernel."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+
+def load(d):
+    f = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1]
+    df = pd.read_csv(f)
+    df["k"] = df["Kernel_Name"].str.extract(r"(k_\w+)")[0]
+    return df
+
+
+def main():
+    root, chunk = sys.argv[1], int(sys.argv[2])
+    fe, wr = load(os.path.join(root, "pmc_FETCH_SIZE")), load(os.path.join(root, "pmc_WRITE_SIZE"))
+    frames = 1024 * 3      # prof_extract.py --pairs 512 --iters 3
+    # calibration: the 1 GiB torch copy (elementwise copy kernel, 16 B per lane) must fetch 2^30 bytes
+    cal = fe[fe.Kernel_Name.str.contains("elementwise|copy|Copy", regex=True) & (fe.Counter_Value > 100000)]
+    cal_kb = float(cal.Counter_Value.max()) if len(cal) else float("nan")
+    factor = (2 ** 30 / 1024.0) / cal_kb if cal_kb == cal_kb else 2.0
+    out = {"chunk": chunk, "fetch_calibration": {"copy_bytes": 2 ** 30, "FETCH_SIZE_kb_reported": cal_kb, "factor": round(factor, 3)},
+           "kernels": {}}
+    for k in sorted(set(fe.k.dropna())):
+        fkb = fe[fe.k == k].Counter_Value.sum()
+        wkb = wr[wr.k == k].Counter_Value.sum()
+        n = frames if k != "k_ratio_compact" else frames
+        out["kernels"][k] = {"fetch_bytes_per_frame_raw": round(fkb * 1024 / n), "fetch_bytes_per_frame": round(fkb * 1024 * factor / n),
+                             "write_bytes_per_frame": round(wkb * 1024 / n)}
+    dst = os.path.join(root, "pmc_traffic_%d.json" % chunk)
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

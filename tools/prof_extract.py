@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--match", action="store_true")
+    ap.add_argument("--calibrate", action="store_true", help="also run a 1 GiB device copy (PMC FETCH_SIZE calibration)")
     a = ap.parse_args()
     import torch
     import aria_slam_amd as A
@@ -38,6 +39,11 @@ def main():
         if a.match:
             mat.match_batch_device(desc.data_ptr() + cap * 32, counts.data_ptr() + 4, desc, counts, B - 1, cap * 32, 0.75,
                                    matches.data_ptr() + cap * 12, nm.data_ptr() + 4, cap)
+    if a.calibrate:
+        src = torch.empty(2 ** 30, dtype=torch.uint8, device=dev).fill_(1)
+        dst = torch.empty_like(src)
+        torch.cuda.synchronize()
+        dst.copy_(src)
     torch.cuda.synchronize()
     ext.check()
     mat.sync()
