@@ -439,7 +439,7 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
     }
     hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
                        d_matches, d_nmatches, match_cap, m->d_err);
-    if (m->prof_enabled) { hipEventRecord(ev.e[3], m->stream); m->prof_pending.push_back(ev); }
+    if (m->prof_enabled) { hipEventRecord(ev.e[3], m->stream); hipStreamSynchronize(m->stream); m->prof_pending.push_back(ev); }
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

@@ -862,6 +862,7 @@ void Profiler::begin(int stage, hipStream_t st) {
 void Profiler::end(hipStream_t st) {
     if (!enabled) return;
     hipEventRecord(cur.stop, st);
+    hipStreamSynchronize(st);     // pin the stop marker to the end of this stage, not to whatever is queued next
     pending.push_back(cur);
 }
 void Profiler::collect() {
