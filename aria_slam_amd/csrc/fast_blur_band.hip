@@ -58,6 +58,13 @@ static BandCfg band_cfg(int w) {
     return best;
 }
 
+// v_mad_u32_u24: full-rate 24-bit multiply-add (operands here are < 2^24)
+__device__ __forceinline__ uint32_t umad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
@@ -100,7 +107,7 @@ __device__ __forceinline__ int fast_score_pk(const uint8_t* c, int pitch) {
     return max(q0, q1) - 1;
 }
 
-template <int TIE_EVEN>
+template <int TIE_EVEN, int NB1>
 __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                         uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
                                                         int* __restrict__ cand_cnt, int* __restrict__ err, int l,
@@ -182,8 +189,10 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     const int fy0 = kEdgeThreshold - 1, fy1 = h - kEdgeThreshold;
     const int thr = P.fast_threshold;
 
-    const int sb = tid / lpr, li = tid - sb * lpr;       // strip, column group
-    if (sb < nb && !(ablate & 2)) {
+    // NB1: a single strip per workgroup (the common case) -- the strip index is then wave-uniform, so the per-row
+    // guards below compile to scalar branches instead of exec-mask updates
+    const int sb = NB1 ? 0 : tid / lpr, li = NB1 ? tid : tid - sb * lpr;       // strip, column group
+    if ((NB1 ? tid < lpr : sb < nb) && !(ablate & 2)) {
         const int x = li * 4;
         const int yb = y0 + sb * kBandR;                  // first output row of this strip
         // per-lane packed masks of the pixels inside the FAST x range (bit 15: px 0/2, bit 31: px 1/3 of a pair)
@@ -239,10 +248,10 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             // operands < 2^24: 24-bit multiplies (v_mad_u32_u24) are full rate, v_mul_lo_u32 is not
-                            uint32_t acc = __umul24(55u, RS[sC][j]) + 32768u;
-                            acc += __umul24(49u, RS[sM1][j] + RS[sP1][j]);
-                            acc += __umul24(34u, RS[sM2][j] + RS[sP2][j]);
-                            acc += __umul24(18u, RS[sM3][j] + RS[sP3][j]);
+                            uint32_t acc = umad24(55u, RS[sC][j], 32768u);
+                            acc = umad24(49u, RS[sM1][j] + RS[sP1][j], acc);
+                            acc = umad24(34u, RS[sM2][j] + RS[sP2][j], acc);
+                            acc = umad24(18u, RS[sM3][j] + RS[sP3][j], acc);
                             if (tie_even_lane && (acc & 0x1FFFFu) == 0x10000u) acc -= 0x10000u;   // exact tie, odd quotient -> even
                             outw |= min(acc >> 16, 255u) << (8 * j);
                         }
@@ -298,22 +307,39 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     const bool ovf = s_ovf != 0;
     const int qn = (ovf || (ablate & 4)) ? 0 : s_qn;
 
-    // ---- dense scoring of the queued survivors (all lanes busy); score >= t <=> FAST-9 corner ----
-    for (int i = tid; i < qn; i += nthr) {
-        const uint32_t ent = s_queue[i];
-        const int ex = ent & 0x7FF, ro = (ent >> 11) & 0x1FFF;
-        const int sc = fast_score_pk(s_pix + (ro + 3) * pitchL + (ex + 4), pitchL);
-        s_queue[i] = sc >= thr ? (ent | ((uint32_t)sc << 24)) : 0u;
-    }
-    STAMP(4);
+    // ---- dense scoring of the queued survivors (all lanes busy); score >= t <=> FAST-9 corner. Two entries per lane
+    //      and iteration: the 2 x 17 LDS gathers overlap, which matters at 2-3 waves per workgroup. Corners are
+    //      compacted to the front part of the queue memory (s_corner) so the later passes only visit corners. ----
+    __shared__ int s_cn;
+    if (tid == 0) s_cn = 0;
     __syncthreads();
+    uint32_t* s_corner = s_queue;          // in-place compaction is safe: a corner's slot index is <= entries consumed
+    // (each iteration reads its entries into registers before any thread of the block writes: see the barrier below)
+    for (int i0 = 0; i0 < qn; i0 += 2 * nthr) {
+        const int ia = i0 + tid, ib = i0 + nthr + tid;
+        const uint32_t ea = ia < qn ? s_queue[ia] : 0u, eb = ib < qn ? s_queue[ib] : 0u;
+        int sa = 0, sb2 = 0;
+        if (ia < qn) sa = fast_score_pk(s_pix + (((ea >> 11) & 0x1FFF) + 3) * pitchL + ((ea & 0x7FF) + 4), pitchL);
+        if (ib < qn) sb2 = fast_score_pk(s_pix + (((eb >> 11) & 0x1FFF) + 3) * pitchL + ((eb & 0x7FF) + 4), pitchL);
+        const bool ca = ia < qn && sa >= thr, cb = ib < qn && sb2 >= thr;
+        __syncthreads();                   // every thread holds its entries of this round in registers
+        const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
+        int base = 0;
+        if (lane == 0 && (ma | mb)) base = atomicAdd(&s_cn, __popcll(ma) + __popcll(mb));
+        base = __shfl(base, 0);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (ca) s_corner[base + __popcll(ma & lt)] = ea | ((uint32_t)sa << 24);
+        if (cb) s_corner[base + __popcll(ma) + __popcll(mb & lt)] = eb | ((uint32_t)sb2 << 24);
+        __syncthreads();
+    }
+    const int cn = ovf ? 0 : s_cn;
     if (!ovf) {
         // the staged pixels are dead: reuse their LDS as the score map (rows ro = 0 .. RB+1, columns x+1)
         for (int i = tid; i < ((RB + 2) * sp) >> 2; i += nthr) reinterpret_cast<uint32_t*>(s_map)[i] = 0u;
         __syncthreads();
-        for (int i = tid; i < qn; i += nthr) {
-            const uint32_t ent = s_queue[i];
-            if (ent) s_map[((ent >> 11) & 0x1FFF) * sp + (ent & 0x7FF) + 1] = (uint8_t)(ent >> 24);
+        for (int i = tid; i < cn; i += nthr) {
+            const uint32_t ent = s_corner[i];
+            s_map[((ent >> 11) & 0x1FFF) * sp + (ent & 0x7FF) + 1] = (uint8_t)(ent >> 24);
         }
         __syncthreads();
     }
@@ -328,14 +354,14 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     if (tid == 0) s_kn = 0;
     __syncthreads();
     STAMP(5);
-    const int n_items = (ablate & 8) ? 0 : (ovf ? RB * wq : qn);
+    const int n_items = (ablate & 8) ? 0 : (ovf ? RB * wq : cn);
     for (int i0 = 0; i0 < n_items; i0 += nthr) {
         const int i = i0 + tid;
         bool keep = false;
         int X = 0, Y = 0, sc = 0;
         if (i < n_items) {
             if (!ovf) {
-                const uint32_t ent = s_queue[i];
+                const uint32_t ent = s_corner[i];
                 X = ent & 0x7FF;
                 const int ro = (ent >> 11) & 0x1FFF;
                 sc = ent >> 24;
@@ -407,8 +433,10 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
                            Profiler* prof) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
     static int ablate = -1;
@@ -445,12 +473,11 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
         hipStream_t s = (use_side && l > 0) ? side[l] : st;
         if (use_side && l > 0) hipStreamWaitEvent(s, ev_fork, 0);
         unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
-        if (P.tie_mode == 1)
-            ARIA_LAUNCH(prof, k_fast_blur_band<1>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand,
-                        D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp);
-        else
-            ARIA_LAUNCH(prof, k_fast_blur_band<0>, grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand,
-                        D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp);
+#define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
+                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp)
+        if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
+        else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
+#undef ARIA_FB_LAUNCH
         if (use_side && l > 0) { hipEventRecord(ev_join[l], s); hipStreamWaitEvent(st, ev_join[l], 0); }
         if (l == stamp_level && d_stamps) {   // diagnostic: print mean phase lengths of this launch
             hipStreamSynchronize(s);
