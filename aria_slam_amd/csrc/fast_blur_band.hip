@@ -28,17 +28,22 @@
 
 namespace aria {
 
-constexpr int kBandR = 32;                 // output rows per strip (one lane walks R + 8 staged rows)
+constexpr int kBandR = 12;                 // output rows per strip (one lane walks R + 8 staged rows)
 constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a strip
 
 // Workgroup geometry for a level of width w: NB vertically stacked strips of R rows share one staged block of
 // NB*R + 8 rows; thread = (strip, 4-px column). NB is chosen so the waves are full even on narrow levels.
 struct BandCfg { int nb, lpr, nthr, qcap; size_t lds; };
-static BandCfg band_cfg(int w) {
-    // LDS budget per workgroup: 48 KB keeps >= 3 workgroups resident per CU. The survivor queue gets whatever the
-    // staged pixels leave, capped at 50 % of the block's pixels (coarse pyramid levels are corner-dense: the compass
-    // test passes 3 % of level-0 pixels but 25-30 % at level 7 on the benchmark frames); it must hold >= 25 %.
-    const size_t budget = 48 * 1024;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static BandCfg band_cfg(int w, int level) {
+    // Occupancy is what this kernel is short of (2-3 waves per SIMD), and LDS is what limits it, so the LDS budget per
+    // workgroup is small and the survivor queue is sized by how corner-dense a level is expected to be: the compass
+    // test passes ~3 % of level-0 pixels but 25-30 % at level 7 on the benchmark frames (coarse levels pack more
+    // structure per pixel). A full queue is not an error: that block takes the slow rescoring path.
+    static const int budget_kb = env_int("ARIA_BAND_BUDGET_KB", 24);
+    static const int q0 = env_int("ARIA_BAND_QPCT0", 15), qstep = env_int("ARIA_BAND_QPCT_STEP", 5);
+    const size_t budget = (size_t)budget_kb * 1024;
+    const int qpct = std::min(50, q0 + qstep * level);
     const int wq = (w + 3) & ~3, lpr = wq >> 2;
     BandCfg best{};
     double best_util = -1.0;
@@ -47,13 +52,12 @@ static BandCfg band_cfg(int w) {
         if (nthr > 512) break;
         const size_t pix = (size_t)(nb * kBandR + 8) * (wq + 8);
         const int px_blk = nb * kBandR * wq;
-        int qcap = px_blk / 2;
-        if (pix + 4 * (size_t)qcap > budget) qcap = pix < budget ? (int)((budget - pix) / 4) : 0;
-        qcap &= ~63;
-        if (nb > 1 && qcap < px_blk / 4) break;
-        if (qcap < 1024) qcap = 1024;                          // very wide levels: a single strip, whatever it costs
+        int qcap = (int)((int64_t)px_blk * qpct / 100);
+        qcap = std::max(512, (qcap + 63) & ~63);
+        const size_t lds = pix + 4 * (size_t)qcap;
+        if (nb > 1 && lds > budget) break;
         const double util = (double)need / nthr;
-        if (util > best_util + 0.02) { best_util = util; best = BandCfg{nb, lpr, nthr, qcap, pix + 4 * (size_t)qcap}; }
+        if (util > best_util + 0.02) { best_util = util; best = BandCfg{nb, lpr, nthr, qcap, lds}; }
     }
     return best;
 }
@@ -467,7 +471,7 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
     if (use_side) hipEventRecord(ev_fork, st);
     for (int l = 0; l < kLevels; l++) {
         const LevelGeom& g = P.lv[l];
-        const BandCfg c = band_cfg(g.w);
+        const BandCfg c = band_cfg(g.w, l);
         const int RB = c.nb * kBandR;
         const dim3 grid((g.h + RB - 1) / RB, n_frames);
         hipStream_t s = (use_side && l > 0) ? side[l] : st;
