@@ -523,18 +523,37 @@ __global__ __launch_bounds__(256) void k_fast_blur(Plan P, FrameSrc S, const uin
 // ------------------------------------------------------------------------------------------------------
 // a6.3-a6.5  one workgroup per (frame, level)
 // ------------------------------------------------------------------------------------------------------
-// orb.cpp HarrisResponses(blockSize 7, k 0.04f)
-__device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, int x, int y) {
+// orb.cpp HarrisResponses(blockSize 7, k 0.04f). The 9x9 neighbourhood is fetched as 3 aligned dwords per row
+// (27 loads) instead of 81 byte gathers -- scattered byte loads are texture-path bound -- and the 9 bytes of a row
+// are cut out of the 12-byte window with v_alignbyte. dword_ok = the level's rows are 4-byte aligned.
+__device__ __forceinline__ void harris_row9(const uint8_t* rowp, int xs, int sh, bool dword_ok, int* out9) {
+    uint32_t w0, w1, w2;
+    if (dword_ok) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(rowp + xs);
+        w0 = q[0]; w1 = q[1]; w2 = q[2];
+    } else {
+        const uint8_t* q = rowp + xs;
+        w0 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        w1 = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+        w2 = (uint32_t)q[8] | ((uint32_t)q[9] << 8) | ((uint32_t)q[10] << 16) | ((uint32_t)q[11] << 24);
+    }
+    const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh);   // bytes sh .. sh+3   = columns 0..3
+    const uint32_t b = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)sh);   // bytes sh+4 .. sh+7 = columns 4..7
+    out9[0] = a & 0xFF; out9[1] = (a >> 8) & 0xFF; out9[2] = (a >> 16) & 0xFF; out9[3] = a >> 24;
+    out9[4] = b & 0xFF; out9[5] = (b >> 8) & 0xFF; out9[6] = (b >> 16) & 0xFF; out9[7] = b >> 24;
+    out9[8] = (w2 >> (8 * sh)) & 0xFF;                                      // byte sh+8          = column 8
+}
+
+__device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, int x, int y, bool dword_ok) {
     int a = 0, b = 0, c = 0;
-    const uint8_t* base = img + (int64_t)(y - 4) * pitch + (x - 4);
+    const int xs = (x - 4) & ~3, sh = (x - 4) & 3;
+    const uint8_t* base = img + (int64_t)(y - 4) * pitch;
     int prev[9], cur[9], nxt[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) { prev[j] = base[j]; cur[j] = base[pitch + j]; }
+    harris_row9(base, xs, sh, dword_ok, prev);
+    harris_row9(base + pitch, xs, sh, dword_ok, cur);
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const uint8_t* rp = base + (int64_t)(i + 2) * pitch;
-#pragma unroll
-        for (int j = 0; j < 9; j++) nxt[j] = rp[j];
+        harris_row9(base + (int64_t)(i + 2) * pitch, xs, sh, dword_ok, nxt);
 #pragma unroll
         for (int j = 1; j <= 7; j++) {
             const int Ix = (cur[j + 1] - cur[j - 1]) * 2 + (prev[j + 1] - prev[j - 1]) + (nxt[j + 1] - nxt[j - 1]);
@@ -599,7 +618,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
             const int x = cd & 0x7FF, y = (cd >> 11) & 0x7FF;
             const int slot = atomicAdd(&s_misc[1], 1);
             if (slot < kSortCap) {
-                const float r = harris_response(img, pitch, x, y);
+                const float r = harris_response(img, pitch, x, y, (l > 0) || S.aligned4);
                 uint32_t u = __float_as_uint(r);
                 u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order integer image of the float
                 s_keys[slot] = ((unsigned long long)(~u) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
@@ -719,86 +738,129 @@ __device__ __forceinline__ int wave_sum(int v) {
 constexpr int kDescR = 18;
 constexpr int kDescRows = 2 * kDescR + 1;   // 37
 constexpr int kDescPitch = 44;              // 11 dwords >= 37 + 3 bytes of alignment slack
+constexpr int kDescDwords = kDescRows * 11; // 407
+constexpr int kDescKp = 8;                  // keypoints per 128-thread workgroup: 2 waves x 4 DPP rows
+constexpr int kIcPitch = 36;                // raw window: 31 rows x 9 dwords (31 + 3 bytes of alignment slack)
+constexpr int kIcDwords = 31 * 9;           // 279
 
-__global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+// sum over the 16 lanes of a DPP row (every lane of the row gets the total)
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return v;
+}
+
+// a6.6 + a6.8. One keypoint per 16-lane DPP row, four per wave: the per-keypoint scalar work (fastAtan2, the
+// deterministic sincos, bookkeeping) is done once per instruction stream for four keypoints instead of once per
+// wave, which is where a wave-per-keypoint layout spent half its instructions. Lane (row r, l16):
+//   IC moments : columns u = 2*l16-15, 2*l16-14 over the 31 rows of the disc, DPP row reduction
+//   rBRIEF     : test 16*it + l16 for it = 0..15; one 64-bit ballot per iteration carries 16 descriptor bits for each
+//                of the four keypoints; lane l16 keeps word l16 and stores its two bytes
+__global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint2* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err, int n_frames, int blocks_per_frame) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kDescRows * kDescPitch];
-    // XCD-aware block -> (frame, slot) map. Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share
-    // one; speed only, never correctness), and each XCD has its own L2. Give every XCD whole frames, so a frame's raw
-    // and blurred patches are fetched into ONE L2 instead of up to eight (PMC: 9.6 MB -> see profiles/ per frame).
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[kDescKp][kDescRows * kDescPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[kDescKp][31 * kIcPitch];
+    // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
+    // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int frame = (j / blocks_per_frame) * 8 + xcd;
     if (frame >= n_frames) return;
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int slot = (j % blocks_per_frame) * 4 + wv;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int slot0 = (j % blocks_per_frame) * kDescKp + wv * 4;      // first of this wave's four slots (one level)
     const int* cnt = sel_cnt + frame * kLevels;
     int l = 0, base = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < kLevels; i++) {
         const int ci = cnt[i];
-        if (i > 0 && slot >= P.lv[i].sel_off) { l = i; base = total; }
+        if (i > 0 && slot0 >= P.lv[i].sel_off) { l = i; base = total; }
         total += ci;
     }
-    if (slot == 0 && lane == 0) counts[frame] = min(total, kp_cap);
-    if (slot >= P.sel_frame_entries) return;
+    if (slot0 == 0 && lane == 0) counts[frame] = min(total, kp_cap);
+    if (slot0 >= P.sel_frame_entries) return;
     const LevelGeom g = P.lv[l];
-    const int i = slot - g.sel_off;
-    if (i >= cnt[l]) return;
-    const int oidx = base + i;
-    if (oidx >= kp_cap) {
-        if (lane == 0) atomicOr(err, ERRBIT_KPCAP);
-        return;
-    }
-    const uint2 sv = sel[(int64_t)frame * P.sel_frame_entries + slot];
+    const int i0 = slot0 - g.sel_off;
+    const int nk = min(4, cnt[l] - i0);                                // valid keypoints of this wave
+    if (nk <= 0) return;
+    const bool valid = grp < nk;
+    const int oidx = base + i0 + grp;
+    const bool fits = oidx < kp_cap;
+    if (valid && !fits && l16 == 0) atomicOr(err, ERRBIT_KPCAP);
+    const uint2 sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
     const int x = sv.x & 0xFFFF, y = sv.x >> 16;
 
     // pattern rows of this lane (independent of the keypoint): issue early
-    int pat[4];
+    int pat[16];
 #pragma unroll
-    for (int w = 0; w < 4; w++) pat[w] = *reinterpret_cast<const int*>(&kPattern31[(w * 64 + lane) * 4]);
+    for (int it = 0; it < 16; it++) pat[it] = *reinterpret_cast<const int*>(&kPattern31[(it * 16 + l16) * 4]);
 
-    // ---- prefetch the blurred 37 x 44 window into LDS (overlaps the intensity-centroid gathers below) ----
+    // ---- stage the blurred 37 x 44 window of each keypoint in LDS (overlaps the moment gathers) ----
     const uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
     const int xs = (x - kDescR) & ~3;                      // dword-aligned first column (keypoints are >= 31 px inside)
-    uint32_t pv[7];
+    uint32_t* sp = reinterpret_cast<uint32_t*>(s_patch[wv * 4 + grp]);
+    for (int k0 = 0; k0 < 26; k0 += 13) {
+        uint32_t pv[13];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int d = lane + 64 * k;                        // dword index in the window, row-major, 11 per row
-        const int r = d / 11, c = d - r * 11;
-        pv[k] = (d < kDescRows * 11) ? *reinterpret_cast<const uint32_t*>(bl + (int64_t)(y - kDescR + r) * g.pitch + xs + 4 * c) : 0u;
-    }
-
-    // ---- orb.cpp ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (integer, order-free) ----
-    int pitch;
-    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
-    const uint8_t* ctr = img + (int64_t)y * pitch + x;
-    constexpr int umax[16] = ARIA_UMAX_LIST;
-    const int u = (lane & 31) - kHalfPatch;
-    const bool lane_ok = (lane & 31) < 31;
-    const int sgn = (lane >> 5) ? -1 : 1;   // lanes 0..30: row +v, lanes 32..62: row -v
-    int m10 = 0, m01 = 0;
-    if (lane_ok && sgn == 1) m10 = u * (int)ctr[u];
+        for (int k = 0; k < 13; k++) {
+            const int d = l16 + 16 * (k0 + k);              // dword index in the window, row-major, 11 per row
+            const int r = d / 11, c = d - r * 11;
+            pv[k] = (d < kDescDwords) ? *reinterpret_cast<const uint32_t*>(bl + (int64_t)(y - kDescR + r) * g.pitch + xs + 4 * c) : 0u;
+        }
 #pragma unroll
-    for (int v = 1; v <= kHalfPatch; v++) {
-        if (lane_ok && abs(u) <= umax[v]) {
-            const int val = ctr[(int64_t)(sgn * v) * pitch + u];
-            m10 += u * val;
-            m01 += sgn * v * val;
+        for (int k = 0; k < 13; k++) {
+            const int d = l16 + 16 * (k0 + k);
+            if (d < kDescDwords) sp[d] = pv[k];
         }
     }
-    // park the window in LDS while the moments reduce
-    uint32_t* sp = reinterpret_cast<uint32_t*>(s_patch[wv]);
+
+    // ---- stage the raw 31 x 36 window too: coalesced dword loads instead of 62 scattered byte gathers per lane
+    //      (the texture path, not HBM or the VALU, was what bounded this kernel) ----
+    int pitch;
+    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
+    const int xr = (x - kHalfPatch) & ~3;
+    const bool raw_dword = (l > 0) || S.aligned4;
+    uint32_t* sr = reinterpret_cast<uint32_t*>(s_raw[wv * 4 + grp]);
+    for (int k0 = 0; k0 < 18; k0 += 9) {
+        uint32_t rv[9];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int d = lane + 64 * k;
-        if (d < kDescRows * 11) sp[d] = pv[k];
+        for (int k = 0; k < 9; k++) {
+            const int d = l16 + 16 * (k0 + k);              // dword index in the raw window, 9 per row
+            const int r = d / 9, c = d - r * 9;
+            const uint8_t* q = img + (int64_t)(y - kHalfPatch + r) * pitch + xr + 4 * c;
+            uint32_t v = 0;
+            if (d < kIcDwords) {
+                if (raw_dword) v = *reinterpret_cast<const uint32_t*>(q);
+                else v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            }
+            rv[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int d = l16 + 16 * (k0 + k);
+            if (d < kIcDwords) sr[d] = rv[k];
+        }
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- orb.cpp ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (integer, order-free) ----
+    const uint8_t* ctr = s_raw[wv * 4 + grp] + kHalfPatch * kIcPitch + (x - xr);
+    constexpr int umax[16] = ARIA_UMAX_LIST;
+    const int ua = 2 * l16 - kHalfPatch, ub = ua + 1;      // ub == 16 for the last lane: outside every row
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+        const int d = umax[v < 0 ? -v : v];
+        const uint8_t* rowp = ctr + v * kIcPitch;
+        if (abs(ua) <= d) { const int val = rowp[ua]; m10 += ua * val; m01 += v * val; }
+        if (abs(ub) <= d) { const int val = rowp[ub]; m10 += ub * val; m01 += v * val; }
+    }
+    m10 = row16_sum(m10);
+    m01 = row16_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- orb.cpp computeOrbDescriptors (WTA_K 2) on the blurred level, samples served from the LDS window ----
@@ -807,31 +869,33 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, FrameSrc S, const uint
     double sd, cd;
     det_sincos((double)ang, sd, cd);
     const float a = (float)cd, b = (float)sd;
-    const uint8_t* bc = s_patch[wv] + kDescR * kDescPitch + (x - xs);     // window address of the keypoint centre
+    const uint8_t* bc = s_patch[wv * 4 + grp] + kDescR * kDescPitch + (x - xs);     // window address of the keypoint centre
     __builtin_amdgcn_wave_barrier();
-    unsigned long long mine = 0;
+    uint32_t mine = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const float px0 = (float)(signed char)(pat[w] & 0xFF), py0 = (float)(signed char)((pat[w] >> 8) & 0xFF);
-        const float px1 = (float)(signed char)((pat[w] >> 16) & 0xFF), py1 = (float)(signed char)((pat[w] >> 24) & 0xFF);
+    for (int it = 0; it < 16; it++) {
+        const float px0 = (float)(signed char)(pat[it] & 0xFF), py0 = (float)(signed char)((pat[it] >> 8) & 0xFF);
+        const float px1 = (float)(signed char)((pat[it] >> 16) & 0xFF), py1 = (float)(signed char)((pat[it] >> 24) & 0xFF);
         const float fx0 = px0 * a - py0 * b, fy0 = px0 * b + py0 * a;
         const float fx1 = px1 * a - py1 * b, fy1 = px1 * b + py1 * a;
         const int t0 = bc[(int)rintf(fy0) * kDescPitch + (int)rintf(fx0)];
         const int t1 = bc[(int)rintf(fy1) * kDescPitch + (int)rintf(fx1)];
         const unsigned long long m = __ballot(t0 < t1);
-        if (lane == w) mine = m;
+        if (l16 == it) mine = (uint32_t)(m >> (16 * grp)) & 0xFFFFu;
     }
-    const int64_t orow = (int64_t)frame * kp_cap + oidx;
-    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + orow * 32)[lane] = mine;
-    if (lane == 0) {
-        aria_keypoint k;
-        k.x = (float)x * g.scale;          // orb.cpp computeKeyPoints: pt *= layerScale[octave]
-        k.y = (float)y * g.scale;
-        k.size = kPatchSize * g.scale;     // size = patchSize * sf
-        k.angle = angle;
-        k.response = __uint_as_float(sv.y);
-        k.octave = l;
-        kps[orow] = k;
+    if (valid && fits) {
+        const int64_t orow = (int64_t)frame * kp_cap + oidx;
+        *reinterpret_cast<uint16_t*>(desc + orow * 32 + 2 * l16) = (uint16_t)mine;
+        if (l16 == 0) {
+            aria_keypoint k;
+            k.x = (float)x * g.scale;          // orb.cpp computeKeyPoints: pt *= layerScale[octave]
+            k.y = (float)y * g.scale;
+            k.size = kPatchSize * g.scale;     // size = patchSize * sf
+            k.angle = angle;
+            k.response = __uint_as_float(sv.y);
+            k.octave = l;
+            kps[orow] = k;
+        }
     }
 }
 
@@ -947,9 +1011,9 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     // ---- a6.6 + a6.8 angle + descriptor ----
     if (prof) prof->begin(STAGE_DESCRIBE, st);
     {
-        const int bpf = (P.sel_frame_entries + 3) / 4;
+        const int bpf = (P.sel_frame_entries + kDescKp - 1) / kDescKp;
         const int frames8 = (n_frames + 7) / 8 * 8;
-        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(256), 0, st, P, S, D.raw, D.blur,
+        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(128), 0, st, P, S, D.raw, D.blur,
                     D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf);
     }
     if (prof) prof->end(st);

@@ -92,7 +92,7 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
         g.cand_cap = cand_cap_scale <= 0 ? worst : std::max(256, std::min(worst, cand_cap_scale * std::max(quota[l], 1)));
         g.cand_off = cand;
         cand += g.cand_cap;
-        g.sel_cap = quota[l] + kSelSlack;
+        g.sel_cap = (quota[l] + kSelSlack + 3) & ~3;   // multiple of 4: a describe wave's 4 keypoints share one level
         g.sel_off = sel;
         sel += g.sel_cap;
         g.tiles_x = (g.w + kTileW - 1) / kTileW;
