@@ -25,7 +25,8 @@ namespace {
 
 constexpr int kMatchTile = 256;
 #ifndef ARIA_KNN_SCALAR
-#define ARIA_KNN_SCALAR 1
+#define ARIA_KNN_SCALAR 0   // measured (tools/microbench/valu_rates.hip): v_xor with an SGPR source costs 4.35 cycles per wave-instruction,
+                            // VGPR-VGPR 2.55 -> the LDS-broadcast form is the faster of the two
 #endif
 constexpr bool kUseScalarTrain = ARIA_KNN_SCALAR != 0;
 
@@ -100,15 +101,16 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
         const int cnt = min(kMatchTile, nt - t0);
         for (int j = 0; j < cnt; j++) {
             const uint4 a = s_t[2 * j], b = s_t[2 * j + 1];
-            int d = __popc(qa.x ^ a.x);
-            d += __popc(qa.y ^ a.y);
-            d += __popc(qa.z ^ a.z);
-            d += __popc(qa.w ^ a.w);
-            d += __popc(qb.x ^ b.x);
-            d += __popc(qb.y ^ b.y);
-            d += __popc(qb.z ^ b.z);
-            d += __popc(qb.w ^ b.w);
-            const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + j);
+            uint32_t d = 0;
+            d = bcnt_acc(qa.x ^ a.x, d);
+            d = bcnt_acc(qa.y ^ a.y, d);
+            d = bcnt_acc(qa.z ^ a.z, d);
+            d = bcnt_acc(qa.w ^ a.w, d);
+            d = bcnt_acc(qb.x ^ b.x, d);
+            d = bcnt_acc(qb.y ^ b.y, d);
+            d = bcnt_acc(qb.z ^ b.z, d);
+            d = bcnt_acc(qb.w ^ b.w, d);
+            const uint32_t key = (d << 16) | (uint32_t)(t0 + j);
             k1 = min(k1, max(k0, key));
             k0 = min(k0, key);
         }
