@@ -113,14 +113,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ARIA_BENCH_REHEARSAL=1: run the N>1 code path on a one-GPU box (every rank on cuda:0, gloo for the barrier and
+    # the max-over-ranks clock). The numbers of such a run mean nothing; it only proves the multi-rank path executes.
+    rehearsal = os.environ.get("ARIA_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if (world == 1 or rehearsal) else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     n_gpus = world
 
     A.load_library()
@@ -180,7 +187,7 @@ def main():
     ext.check()
     mat.sync()
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=("cpu" if rehearsal else dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
