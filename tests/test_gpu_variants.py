@@ -1,0 +1,31 @@
+"""Alternative kernel paths (selected by environment variables, read once per process) must give the same bits:
+the 64x32 tile FAST/blur kernel, direct-gather resize, the fused in-LDS pyramid, per-level side streams, and --
+by shrinking the survivor queue to 1 % -- the dense-rescoring slow path of the band kernel."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = [
+    {},
+    {"ARIA_FAST_BLUR_IMPL": "tile"},
+    {"ARIA_RESIZE_IMPL": "direct"},
+    {"ARIA_PYRAMID_IMPL": "fused"},
+    {"ARIA_LEVEL_STREAMS": "1"},
+    {"ARIA_BAND_QPCT0": "1", "ARIA_BAND_QPCT_STEP": "0"},          # survivor queue overflows -> slow path
+    {"ARIA_BAND_BUDGET_KB": "160"},                                # several strips per workgroup
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_variant_matches_golden(env):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_check.py")], env=e, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("OK") == 3

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Extract + match two golden cases on the GPU and compare with tests/golden/golden.json (no oracle needed).
+Used by tests/test_gpu_variants.py to check alternative kernel paths selected through environment variables."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import aria_slam_amd as A  # noqa: E402
+
+
+def sha(x):
+    return hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
+
+
+def main():
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    bad = 0
+    for key in ("s1_640x480_n2000", "s3_333x251_n300", "s7_752x480_n1000"):
+        g = gold[key]
+        s, wh, n = key.split("_")
+        w, h = (int(v) for v in wh.split("x"))
+        a, b = A.synth_frame_pair(int(s[1:]), w, h)
+        e = A.OrbHipExtractor(max_features=int(n[1:]), max_width=w, max_height=h)
+        m = A.HipMatcher()
+        fa, fb = e.extract(a), e.extract(b)
+        ok = (sha(fa["keypoints"]) == g["kp_a"] and sha(fa["descriptors"]) == g["desc_a"] and
+              sha(fb["keypoints"]) == g["kp_b"] and sha(fb["descriptors"]) == g["desc_b"] and
+              sha(m.match(fb, fa, None, 0.75)) == g["matches"])
+        print(key, "OK" if ok else "MISMATCH")
+        bad += 0 if ok else 1
+        e.close()
+        m.close()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
