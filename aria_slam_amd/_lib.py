@@ -22,7 +22,7 @@ EXPORTS = [
     "aria_status_string", "aria_abi_version", "aria_last_hip_error",
     "aria_orb_default_config", "aria_orb_create", "aria_orb_destroy", "aria_orb_set_max_features",
     "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_extract", "aria_orb_extract_async",
-    "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream",
+    "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream", "aria_orb_slow_path_blocks",
     "aria_orb_set_profiling", "aria_orb_get_profile", "aria_matcher_set_profiling", "aria_matcher_get_profile",
     "aria_orb_level_info", "aria_orb_resize_table", "aria_orb_pyramid_bands", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
     "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
@@ -119,6 +119,8 @@ def load_library():
     L.aria_orb_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.aria_orb_check.argtypes = [C.c_void_p]
+    L.aria_orb_slow_path_blocks.argtypes = [C.c_void_p, C.c_int]
+    L.aria_orb_slow_path_blocks.restype = C.c_longlong
     L.aria_orb_stream.argtypes = [C.c_void_p]
     L.aria_orb_set_max_features.argtypes = [C.c_void_p, C.c_int]
     L.aria_orb_get_max_features.argtypes = [C.c_void_p]

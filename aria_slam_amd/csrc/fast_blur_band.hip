@@ -35,13 +35,16 @@ constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a st
 // NB*R + 8 rows; thread = (strip, 4-px column). NB is chosen so the waves are full even on narrow levels.
 struct BandCfg { int nb, lpr, nthr, qcap; size_t lds; };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static BandCfg band_cfg(int w, int level) {
+static BandCfg band_cfg(const Plan& P, int w, int level) {
     // Occupancy is what this kernel is short of (2-3 waves per SIMD), and LDS is what limits it, so the LDS budget per
     // workgroup is small and the survivor queue is sized by how corner-dense a level is expected to be: the compass
     // test passes ~3 % of level-0 pixels but 25-30 % at level 7 on the benchmark frames (coarse levels pack more
-    // structure per pixel). A full queue is not an error: that block takes the slow rescoring path.
-    static const int budget_kb = env_int("ARIA_BAND_BUDGET_KB", 24);
-    static const int q0 = env_int("ARIA_BAND_QPCT0", 15), qstep = env_int("ARIA_BAND_QPCT_STEP", 5);
+    // structure per pixel). A full queue is not an error: that block takes the slow rescoring path and is counted
+    // (aria_orb_slow_path_blocks); the host raises band_qpct0 when it sees such blocks.
+    static const int env_budget = env_int("ARIA_BAND_BUDGET_KB", 0), env_q0 = env_int("ARIA_BAND_QPCT0", -1),
+                     env_qs = env_int("ARIA_BAND_QPCT_STEP", -1);
+    const int budget_kb = env_budget > 0 ? env_budget : P.band_budget_kb;
+    const int q0 = env_q0 >= 0 ? env_q0 : P.band_qpct0, qstep = env_qs >= 0 ? env_qs : P.band_qstep;
     const size_t budget = (size_t)budget_kb * 1024;
     const int qpct = std::min(50, q0 + qstep * level);
     const int wq = (w + 3) & ~3, lpr = wq >> 2;
@@ -115,7 +118,8 @@ template <int TIE_EVEN, int NB1>
 __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                         uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
                                                         int* __restrict__ cand_cnt, int* __restrict__ err, int l,
-                                                        int nb, int qcap, int ablate, unsigned long long* __restrict__ stamps) {
+                                                        int nb, int qcap, int ablate, unsigned long long* __restrict__ stamps,
+                                                        int* __restrict__ slow_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_qn, s_ovf;
     // diagnostic build only (ARIA_STAMPS=1): phase boundaries of wave 0 of every workgroup, s_memtime ticks
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     int* ccnt = cand_cnt + frame * kLevels + l;
     const int lane = tid & 63;
     const bool ovf = s_ovf != 0;
+    if (ovf && tid == 0) atomicAdd(slow_blocks, 1);
     const int qn = (ovf || (ablate & 4)) ? 0 : s_qn;
 
     // ---- dense scoring of the queued survivors (all lanes busy); score >= t <=> FAST-9 corner. Two entries per lane
@@ -471,14 +476,14 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
     if (use_side) hipEventRecord(ev_fork, st);
     for (int l = 0; l < kLevels; l++) {
         const LevelGeom& g = P.lv[l];
-        const BandCfg c = band_cfg(g.w, l);
+        const BandCfg c = band_cfg(P, g.w, l);
         const int RB = c.nb * kBandR;
         const dim3 grid((g.h + RB - 1) / RB, n_frames);
         hipStream_t s = (use_side && l > 0) ? side[l] : st;
         if (use_side && l > 0) hipStreamWaitEvent(s, ev_fork, 0);
         unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
 #define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
-                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp)
+                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1)
         if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
         else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
 #undef ARIA_FB_LAUNCH

@@ -27,6 +27,8 @@ struct aria_orb_s {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 0;
+    int band_qpct0 = 15;            // survivor-queue size of the band kernel at level 0 (% of a workgroup's pixels); self-tuned
+    long long slow_blocks = 0;      // band-kernel workgroups that overflowed their queue since the last reset
 
     Plan plan{};            // plan of the most recent (width, height)
     bool plan_valid = false;
@@ -70,6 +72,14 @@ void free_scratch(aria_orb_s* h) {
 
 // Size everything for (max_w, max_h, max_features, max_batch). Level sizes are monotone in width/height, so a
 // plan for any smaller image fits.
+// Self-tuning of the band kernel's survivor queue: blocks that overflowed it took the (correct but ~20x slower) dense
+// rescoring path; give the next calls a larger queue (at most 50 % of a workgroup's pixels).
+void note_slow_blocks(aria_orb_s* h, int n) {
+    if (n <= 0) return;
+    h->slow_blocks += n;
+    if (h->band_qpct0 < 50) h->band_qpct0 = std::min(50, h->band_qpct0 + 10);
+}
+
 int alloc_scratch(aria_orb_s* h) {
     Plan mp;
     int64_t tabn = plan_tab_entries(h->max_w, h->max_h) + 64;
@@ -89,8 +99,8 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
     h->bands_host.assign((size_t)((h->max_h + 7) / 8) * kLevels * 4 + 64, 0);
     ARIA_HIP(hipMalloc(&h->D.pyr_bands, sizeof(int) * h->bands_host.size()));
-    ARIA_HIP(hipMalloc(&h->D.err, sizeof(int)));
-    ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
+    ARIA_HIP(hipMalloc(&h->D.err, 2 * sizeof(int)));     // [0] deferred error bits, [1] band-kernel slow-path blocks
+    ARIA_HIP(hipMemset(h->D.err, 0, 2 * sizeof(int)));
     const size_t img_bytes = (size_t)align_up(h->max_w, 16) * h->max_h;
     ARIA_HIP(hipMalloc(&h->d_img, img_bytes));
     ARIA_HIP(hipHostMalloc(&h->h_img, img_bytes));
@@ -99,19 +109,22 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->d_count, sizeof(int)));
     ARIA_HIP(hipHostMalloc(&h->h_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
     ARIA_HIP(hipHostMalloc(&h->h_desc, 32 * (size_t)h->kp_cap));
-    ARIA_HIP(hipHostMalloc(&h->h_count, 2 * sizeof(int)));
+    ARIA_HIP(hipHostMalloc(&h->h_count, 4 * sizeof(int)));
     h->plan_valid = false;
     return ARIA_OK;
 }
 
 int ensure_plan(aria_orb_s* h, int w, int ht) {
     if (w > h->max_w || ht > h->max_h) return ARIA_E_TOO_LARGE;
-    if (h->plan_valid && h->plan.width == w && h->plan.height == ht && h->plan.nfeatures == h->max_features)
+    if (h->plan_valid && h->plan.width == w && h->plan.height == ht && h->plan.nfeatures == h->max_features) {
+        h->plan.band_qpct0 = h->band_qpct0;
         return ARIA_OK;
+    }
     int used = 0;
     int rc = build_plan(w, ht, h->max_features, h->cand_cap_scale, h->tie_mode, &h->plan, h->tab_host.data(),
                         (int)h->tab_host.size(), &used);
     if (rc != ARIA_OK) return rc;
+    h->plan.band_qpct0 = h->band_qpct0;
     if (used > 0)
         ARIA_HIP(hipMemcpyAsync(h->D.tab, h->tab_host.data(), sizeof(uint32_t) * (size_t)used, hipMemcpyHostToDevice,
                                 h->stream));
@@ -138,14 +151,15 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     ARIA_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
     ARIA_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, 32 * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
     ARIA_HIP(hipMemcpyAsync(&h->h_count[0], h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemcpyAsync(&h->h_count[1], h->D.err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemsetAsync(h->D.err, 0, sizeof(int), h->stream));
+    ARIA_HIP(hipMemcpyAsync(&h->h_count[1], h->D.err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipMemsetAsync(h->D.err, 0, 2 * sizeof(int), h->stream));
     return ARIA_OK;
 }
 
 int finish_single(aria_orb_s* h, aria_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     ARIA_HIP(hipStreamSynchronize(h->stream));
     const int errbits = h->h_count[1];
+    note_slow_blocks(h, h->h_count[2]);
     int st = errbits_to_status(errbits & ~ERRBIT_KPCAP);
     if (st != ARIA_OK) { if (n_out) *n_out = 0; return st; }
     const int n = h->h_count[0];
@@ -317,10 +331,18 @@ int aria_orb_check(aria_orb_t h) {
     if (!h) return ARIA_E_INVALID;
     ARIA_HIP(hipSetDevice(h->device));
     ARIA_HIP(hipStreamSynchronize(h->stream));
-    int bits = 0;
-    ARIA_HIP(hipMemcpy(&bits, h->D.err, sizeof(int), hipMemcpyDeviceToHost));
-    if (bits) ARIA_HIP(hipMemset(h->D.err, 0, sizeof(int)));
-    return errbits_to_status(bits);
+    int two[2] = {0, 0};
+    ARIA_HIP(hipMemcpy(two, h->D.err, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    if (two[0] || two[1]) ARIA_HIP(hipMemset(h->D.err, 0, 2 * sizeof(int)));
+    note_slow_blocks(h, two[1]);
+    return errbits_to_status(two[0]);
+}
+
+long long aria_orb_slow_path_blocks(aria_orb_t h, int reset) {
+    if (!h) return ARIA_E_INVALID;
+    const long long n = h->slow_blocks;
+    if (reset) h->slow_blocks = 0;
+    return n;
 }
 
 int aria_orb_set_profiling(aria_orb_t h, int enable) {

@@ -53,6 +53,9 @@ struct Plan {
     int tie_mode;
     int fast_threshold;
     int sort_cap;             // power of two in [kSortCapMin, kSortCapMax]
+    // band kernel tuning: survivor-queue size = min(50, band_qpct0 + band_qstep * level) % of a workgroup's pixels;
+    // LDS budget (KB) above which a workgroup is not given a second strip
+    int band_qpct0, band_qstep, band_budget_kb;
     // fused pyramid kernel: a workgroup owns pyr_bh level-0 rows and builds the matching rows of levels 1..7 in LDS
     int pyr_bh, pyr_nbands, pyr_lds_bytes;
     int pyr_off[kLevels];     // LDS byte offset of the level-l row buffer (level 0: the staged source band)

@@ -113,6 +113,9 @@ class OrbHipExtractor:
     def check(self):
         check(self._L.aria_orb_check(self._h), "aria_orb_check")
 
+    def slow_path_blocks(self, reset=False):
+        return self._L.aria_orb_slow_path_blocks(self._h, int(reset))
+
     STAGES = ("resize", "fast_blur", "select", "describe")
 
     def set_profiling(self, enable):

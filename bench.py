@@ -191,6 +191,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    slow_blocks = ext.slow_path_blocks(reset=True)      # band-kernel workgroups that fell back to dense rescoring
     prof_e, prof_frames = ext.get_profile(reset=True)
     prof_m, prof_pairs = mat.get_profile(reset=True)
     cnt_host = counts.cpu().numpy()
@@ -246,7 +247,8 @@ def main():
                        "frames_per_gpu_per_step": B, "chunk_frames": args.chunk, "ratio": args.ratio,
                        "parallelism": "frames sharded by contiguous range, %d rank(s), no collective" % n_gpus,
                        "mean_keypoints_per_frame": round(float(cnt_host.mean()), 2),
-                       "mean_matches_per_frame": round(float(nm_host.mean()), 2)},
+                       "mean_matches_per_frame": round(float(nm_host.mean()), 2),
+                       "slow_path_blocks": int(slow_blocks)},
             "roofline": roofline,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -113,6 +113,10 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
 /* Synchronises the handle's stream and returns ARIA_OK or the first deferred error (overflow flags). */
 int aria_orb_check(aria_orb_t h);
 void* aria_orb_stream(aria_orb_t h);
+/* Diagnostics: FAST+blur workgroups whose survivor queue overflowed (corner-dense image regions) and that therefore
+ * took the slower dense-rescoring path -- results are identical either way. Counted when aria_orb_extract /
+ * aria_orb_sync / aria_orb_check read the device state; the handle enlarges the queue for later calls by itself. */
+long long aria_orb_slow_path_blocks(aria_orb_t h, int reset);
 
 /* Per-stage device timing for bench.py's roofline figure (no reference counterpart): when enabled, HIP events
  * are recorded on the handle's stream around each stage of every internal pass.

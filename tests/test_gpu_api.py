@@ -373,3 +373,25 @@ def test_config3_batch_checksum_of_checksums(aria, torch_cuda):
         assert hb.hexdigest() == hs.hexdigest()
     finally:
         e.close()
+
+
+def test_survivor_queue_self_tunes_on_corner_dense_images(aria, oracle):
+    """A noise image overflows the band kernel's survivor queue: those workgroups take the dense-rescoring path
+    (same bits), are counted, and the handle enlarges the queue so later frames avoid it."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    ok, od = oracle.orb_extract(img, oracle.default_params(1000))
+    e = _ext(aria, nf=1000)
+    try:
+        slow = []
+        for _ in range(5):
+            f = e.extract(img)
+            assert f["keypoints"].tobytes() == ok.tobytes() and np.array_equal(f["descriptors"], od)
+            slow.append(e.slow_path_blocks(reset=True))
+        assert slow[0] > 0, slow
+        assert slow[-1] < slow[0], slow
+        a, _ = aria.synth_frame_pair(1)
+        e.extract(a)
+        assert e.slow_path_blocks() == 0
+    finally:
+        e.close()
