@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.h"
+#include "match_kernels.h"
 
 using namespace aria;
 
@@ -193,6 +194,7 @@ struct aria_matcher_s {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int max_query = 0, max_train = 0;
+    bool knn_valu = false;          // ARIA_KNN_IMPL=valu: the vector-ALU kernel below instead of the matrix-core one
     uint2* d_keys = nullptr;        // grow-only scratch: [n_pairs][maxq]
     size_t keys_cap = 0;
     int* d_err = nullptr;
@@ -235,6 +237,22 @@ struct aria_matcher_s {
 };
 
 namespace {
+
+// kNN-2 of every (query block, pair): matrix-core kernel (knn2_mfma.hip) unless the handle asks for the VALU one
+void launch_knn2(aria_matcher_s* m, int mode, dim3 grid, const uint8_t* q, const int* nq_arr, int nq_fixed,
+                 const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* keys,
+                 int maxq, double ratio, int* good) {
+    if (!m->knn_valu) {
+        launch_knn2_mfma(mode, grid, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride, keys, maxq,
+                         ratio, good);
+    } else if (mode == 0) {
+        hipLaunchKernelGGL(k_knn2<0>, grid, dim3(256), 0, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
+                           t_stride, keys, maxq, ratio, good);
+    } else {
+        hipLaunchKernelGGL(k_knn2<1>, grid, dim3(256), 0, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
+                           t_stride, keys, maxq, ratio, good);
+    }
+}
 
 int ensure_keys(aria_matcher_s* m, size_t entries) {
     if (entries <= m->keys_cap) return ARIA_OK;
@@ -308,6 +326,7 @@ int aria_matcher_create(const aria_matcher_config* c, aria_matcher_t* out) {
     m->device = c->device;
     m->max_query = c->max_query;
     m->max_train = c->max_train;
+    { const char* e = getenv("ARIA_KNN_IMPL"); m->knn_valu = e && std::strcmp(e, "valu") == 0; }
     if (c->stream) {
         m->stream = (hipStream_t)c->stream;
     } else {
@@ -374,8 +393,8 @@ int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t
     ARIA_HIP(hipSetDevice(m->device));
     int rc = upload_pair(m, q, nq, t, nt);
     if (rc != ARIA_OK) return rc;
-    hipLaunchKernelGGL(k_knn2<0>, dim3((nq + 255) / 256, 1), dim3(256), 0, m->stream, m->d_q, nullptr, nq, m->d_t,
-                       nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys, m->max_query, 0.0, nullptr);
+    launch_knn2(m, 0, dim3((nq + 255) / 256, 1), m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
+                m->max_query, 0.0, nullptr);
     hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
                        m->d_m, m->d_n, m->max_query, m->d_err);
     ARIA_HIP(hipGetLastError());
@@ -400,8 +419,8 @@ int aria_matcher_knn2(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t*
     ARIA_HIP(hipSetDevice(m->device));
     int rc = upload_pair(m, q, nq, t ? t : q, nt);
     if (rc != ARIA_OK) return rc;
-    hipLaunchKernelGGL(k_knn2<0>, dim3((nq + 255) / 256, 1), dim3(256), 0, m->stream, m->d_q, nullptr, nq, m->d_t,
-                       nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys, m->max_query, 0.0, nullptr);
+    launch_knn2(m, 0, dim3((nq + 255) / 256, 1), m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
+                m->max_query, 0.0, nullptr);
     hipLaunchKernelGGL(k_unpack_knn, dim3((nq + 255) / 256), dim3(256), 0, m->stream, m->d_keys, nq, m->d_idx,
                        m->d_idx + 2 * (size_t)m->max_query);
     ARIA_HIP(hipGetLastError());
@@ -432,8 +451,8 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
         hipStreamSynchronize(m->stream);
         hipEventRecord(ev.e[0], m->stream);
     }
-    hipLaunchKernelGGL(k_knn2<0>, dim3((unsigned)((maxq + 255) / 256), n_pairs), dim3(256), 0, m->stream, d_query, d_nq,
-                       0, d_train, d_nt, 0, desc_stride, desc_stride, m->d_keys, (int)maxq, 0.0, nullptr);
+    launch_knn2(m, 0, dim3((unsigned)((maxq + 255) / 256), n_pairs), d_query, d_nq, 0, d_train, d_nt, 0, desc_stride,
+                desc_stride, m->d_keys, (int)maxq, 0.0, nullptr);
     if (m->prof_enabled) {
         hipEventRecord(ev.e[1], m->stream);
         hipStreamSynchronize(m->stream);
@@ -455,8 +474,8 @@ int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int n
     ARIA_HIP(hipSetDevice(m->device));
     ARIA_HIP(hipMemsetAsync(d_good, 0, sizeof(int) * (size_t)n_kf, m->stream));
     if (nq == 0) return ARIA_OK;
-    hipLaunchKernelGGL(k_knn2<1>, dim3((nq + 255) / 256, n_kf), dim3(256), 0, m->stream, d_query, nullptr, nq, d_db,
-                       d_kf_counts, 0, (int64_t)0, desc_stride, nullptr, 0, ratio, d_good);
+    launch_knn2(m, 1, dim3((nq + 255) / 256, n_kf), d_query, nullptr, nq, d_db, d_kf_counts, 0, (int64_t)0, desc_stride,
+                nullptr, 0, ratio, d_good);
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

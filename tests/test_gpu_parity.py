@@ -73,3 +73,37 @@ def test_match_indices_identical(aria, oracle):
     finally:
         e.close()
         m.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (31, 33), (64, 64), (65, 63), (257, 129), (300, 1), (2000, 1999),
+                                   (513, 4095)])
+def test_knn2_random_sets_with_ties(aria, oracle, nq, nt):
+    """Raw descriptor sets (no extractor): sizes off every tile boundary of the matrix-core kernel (32-column /
+    64-train tiles, 256-query workgroups), low-entropy descriptors so equal distances and duplicates are common
+    (ties must go to the lower train index, like cv::BFMatcher's in-order scan), all-zero and all-one rows."""
+    rng = np.random.default_rng(1000 * nq + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q[:, 4:] &= 0x11                      # few distinct values -> many ties
+    t[:, 4:] &= 0x11
+    if nt > 8:
+        t[nt // 2] = t[1]                 # exact duplicates at different indices
+        t[nt - 1] = t[1]
+        t[3] = 0
+        t[5] = 255
+    if nq > 4:
+        q[2] = 0
+        q[3] = 255
+        q[4] = t[min(1, nt - 1)]
+    m = aria.HipMatcher()
+    try:
+        idx, dist = m.knn2({"descriptors": q}, {"descriptors": t})
+        oidx, odist = oracle.knn2(q, t)
+        assert np.array_equal(dist, odist)
+        assert np.array_equal(idx, oidx)
+        for ratio in (0.75, 0.0):
+            got = m.match({"descriptors": q}, {"descriptors": t}, None, ratio)
+            want = oracle.match_ratio(q, t, ratio)
+            assert got.tobytes() == want.tobytes()
+    finally:
+        m.close()

@@ -1,5 +1,5 @@
 """Alternative kernel paths (selected by environment variables, read once per process) must give the same bits:
-the 64x32 tile FAST/blur kernel, direct-gather resize, the fused in-LDS pyramid, per-level side streams, and --
+the 64x32 tile FAST/blur kernel, direct-gather resize, the fused in-LDS pyramid, per-level side streams, the vector-ALU kNN-2, and --
 by shrinking the survivor queue to 1 % -- the dense-rescoring slow path of the band kernel."""
 import os
 import subprocess
@@ -18,6 +18,7 @@ VARIANTS = [
     {"ARIA_LEVEL_STREAMS": "1"},
     {"ARIA_BAND_QPCT0": "1", "ARIA_BAND_QPCT_STEP": "0"},          # survivor queue overflows -> slow path
     {"ARIA_BAND_BUDGET_KB": "160"},                                # several strips per workgroup
+    {"ARIA_KNN_IMPL": "valu"},                                     # vector-ALU kNN-2 instead of the matrix-core one
 ]
 
 
