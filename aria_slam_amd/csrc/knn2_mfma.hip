@@ -4,20 +4,26 @@
 //
 // The 2000 x 2000 x 256-bit distance table of one frame pair is the one GEMM-shaped piece of this path -- it is
 // compute-bound (160 KB in, 4M distances), not HBM-bound -- and for bit vectors
-//     hamming(q, t) = popcount(q) + popcount(t) - 2 * <q, t>
-// where <q, t> is the number of common set bits. With every bit widened to a 0/1 byte that inner product is an
-// exact int8 x int8 -> int32 matrix product, v_mfma_i32_32x32x32_i8: one instruction = 32 trains x 32 queries x
-// 32 bits (32 cycles), against 8 x (v_xor + v_bcnt) per single pair on the vector ALU. All arithmetic is integer,
-// so the result is bit-identical to the VALU kernel.
+//     hamming(q, t) = popcount(q) + popcount(t) - 2 |q & t|,
+// where |q & t| (the number of common set bits) is an exact int8 x int8 -> int32 matrix product once every bit is
+// widened to a byte: v_mfma_i32_32x32x32_i8, one instruction = 32 trains x 32 queries x 32 bits in 32 cycles, against
+// 8 x (v_xor + v_bcnt) per single pair on the vector ALU. The bytes are scaled (train bit -> -128, query bit -> 64)
+// and the accumulator is preloaded with 4096 popcount(t) + train index, so that the MFMA itself delivers the sortable
+// key  4096 (popcount(t) - 2 |q & t|) + index  and the vector ALU is left with exactly the running top-2 (two
+// v_med3 per distance). All arithmetic is integer: bit-identical to the VALU kernel.
+// Why single-bit bytes (0x80 / 0x40 / 0) and not +-1 or +-127: the matrix pipe's clock gives way under load by
+// operand toggle rate (tools/microbench/mfma_i8_power.hip: 16.3 ns per MFMA per SIMD on zeros, 17.2 on single-bit
+// bytes, 20.4 on +-64 x +-127, 22.1 on random bytes) -- the sparse encoding is worth 15 % of the kernel.
 //
-// Workgroup = 4 waves = 256 queries; a wave keeps the widened fragments of its 64 queries (2 column tiles, 64 VGPRs)
+// Workgroup = 4 waves; a wave keeps the widened fragments of its 32*NC queries (NC column tiles, 32 VGPRs each)
 // resident and walks the train set in tiles of 64 that the workgroup widens once into LDS (double-buffered).
 // A = trains (rows), B = queries (columns): the accumulator then has the query on the lane and 16 trains in the
-// registers, so the running top-2 is a per-lane min/med3 chain with no cross-lane traffic until the very end.
+// registers, so the top-2 is a per-lane chain with no cross-lane traffic until the very end.
 // The k order inside a fragment does not matter (a dot product), only that A and B split K the same way, which the
 // symmetric A/B lane maps guarantee: lane l carries row/column l & 31 and K-half l >> 5.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "common.h"
@@ -29,152 +35,190 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kQB = 256;             // queries per workgroup
-constexpr int kTT = 64;              // trains per staged tile (two row tiles of 32)
 constexpr int kRowB = 272;           // LDS bytes per widened train: 256 + 16 (bank spread for the ds_read_b128 fragments)
-constexpr int kNone = 0x7FFFFFFF;    // key of "no train"
+constexpr int kNone = 0x70000000;    // accumulator preload of a train row past the end; any key >= kNoneMin is "no train"
+constexpr int kNoneMin = 0x60000000;
+constexpr int kKeyBias = 0x00800000; // keys live in [kKeyBias, 2^31): as IEEE bit patterns they are positive NORMAL floats,
+                                     // whose order is the integer order -- the top-2 then runs on v_med3_f32, which the
+                                     // compiler knows (MFMA hazards, scheduling groups); there is no integer med3 builtin
 
-// 4 descriptor bits -> 4 bytes of 0/1 (bit k lands at 8k: n + n<<7 + n<<14 + n<<21, the partial products never overlap)
-__device__ __forceinline__ int widen4(uint32_t n) { return (int)((n * 0x00204081u) & 0x01010101u); }
-__device__ __forceinline__ v4i widen16(uint32_t hw) {
+// Key layouts (c = |q & t|, pt = popcount(t); popcount(q) is added at the very end).
+// NARROW (train sets up to 4096 descriptors -- every SLAM frame): train bit -> 0x80 (-128), query bit -> 0x40 (64),
+//   product sum = -8192 c; preload = 4096 (pt + 256) + index + bias  ->  key = 4096 (pt - 2c + 256) + index + bias.
+// WIDE (up to 65535): query bit -> 0x01, product sum = -128 c; key = (sum << 10) + ((pt + 256) << 16 | index) + bias,
+//   one extra v_lshl_add per distance.
+constexpr int kNarrowMax = 4096;
+
+// 4 descriptor bits -> 4 bytes with bit k in byte k (the partial products n << 7k never overlap, so no carries)
+__device__ __forceinline__ int spread4(uint32_t n, uint32_t mul, uint32_t mask) { return (int)((n * mul) & mask); }
+template <bool WIDE>
+__device__ __forceinline__ v4i widen_train16(uint32_t hw) {      // set bit -> 0x80
     v4i r;
-    r.x = widen4(hw & 15u);
-    r.y = widen4((hw >> 4) & 15u);
-    r.z = widen4((hw >> 8) & 15u);
-    r.w = widen4((hw >> 12) & 15u);
+    r.x = spread4(hw & 15u, 0x10204080u, 0x80808080u);
+    r.y = spread4((hw >> 4) & 15u, 0x10204080u, 0x80808080u);
+    r.z = spread4((hw >> 8) & 15u, 0x10204080u, 0x80808080u);
+    r.w = spread4((hw >> 12) & 15u, 0x10204080u, 0x80808080u);
     return r;
 }
-__device__ __forceinline__ int mad_i24(int a, int b, int c) {
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ int med3_i32(int a, int b, int c) {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+template <bool WIDE>
+__device__ __forceinline__ v4i widen_query16(uint32_t hw) {      // set bit -> 0x40 (NARROW) / 0x01 (WIDE)
+    const uint32_t mul = WIDE ? 0x00204081u : 0x08102040u, mask = WIDE ? 0x01010101u : 0x40404040u;
+    v4i r;
+    r.x = spread4(hw & 15u, mul, mask);
+    r.y = spread4((hw >> 4) & 15u, mul, mask);
+    r.z = spread4((hw >> 8) & 15u, mul, mask);
+    r.w = spread4((hw >> 12) & 15u, mul, mask);
     return r;
 }
 
-struct StageRegs { uint32_t d0, d1; uint4 a, b; };
+// sum over the aligned group of 8 lanes (DPP: xor 1, xor 2 inside the quad, then the half-row mirror)
+__device__ __forceinline__ int sum8(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    return v;
+}
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed,
-                                                   const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed,
-                                                   int64_t q_stride, int64_t t_stride, uint2* __restrict__ keys, int maxq,
-                                                   double ratio, int* __restrict__ good) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][kTT * kRowB];
-    __shared__ __attribute__((aligned(16))) int s_base[2][kTT];
+// (m1 <= m2) <- the two smallest of {m1, m2, key}; all three are positive normal floats by bit pattern, so
+// min(a, b) = med3(a, b, +0) and no NaN/denormal rule is ever involved (fminf would add a canonicalising v_max)
+__device__ __forceinline__ void top2_update(float& m1, float& m2, int key) {
+    const float k = __int_as_float(key);
+    const float n2 = __builtin_amdgcn_fmed3f(m1, m2, k);
+    m1 = __builtin_amdgcn_fmed3f(m1, k, 0.0f);
+    m2 = n2;
+}
+
+// key -> (distance << 16 | train index), the form the rest of the matcher uses
+template <bool WIDE>
+__device__ __forceinline__ uint32_t final_key(int k, int pq) {
+    if (k >= kNoneMin) return 0xFFFFFFFFu;
+    const uint32_t u = (uint32_t)(k - kKeyBias);
+    if (WIDE) return u + ((uint32_t)(pq - 256) << 16);
+    return (((u >> 12) + (uint32_t)(pq - 256)) << 16) | (u & 4095u);
+}
+
+template <int MODE, bool WIDE, int NC, int TT>   // NC column tiles (of 32 queries) per wave: workgroup = 128 NC queries;
+                                                 // TT trains per staged tile (= per barrier)
+__device__ __forceinline__ void knn2_body(
+    const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, const uint8_t* __restrict__ t,
+    const int* __restrict__ nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* __restrict__ keys, int maxq,
+    double ratio, int* __restrict__ good) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][TT * kRowB];
+    __shared__ __attribute__((aligned(16))) int s_base[2][TT];    // [buf][train of the tile]: accumulator preload
     __shared__ int s_cnt;
+    constexpr int QB = 128 * NC;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, hh = lane >> 5;
     const int pair = blockIdx.y;
     const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
     const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
-    if ((int)blockIdx.x * kQB >= nq) return;
+    if ((int)blockIdx.x * QB >= nq) return;
     const uint4* qp = reinterpret_cast<const uint4*>(q + (int64_t)pair * q_stride);
     const uint32_t* tw = reinterpret_cast<const uint32_t*>(t + (int64_t)pair * t_stride);
-    const uint4* tp = reinterpret_cast<const uint4*>(t + (int64_t)pair * t_stride);
 
     // resident B fragments: column tile c, k-step s = bits [32 s + 16 hh, +16) of query q0 + 32 c + col
-    const int q0 = blockIdx.x * kQB + wv * 64;
-    v4i B[2][8];
-    int pq[2];
+    const int q0 = blockIdx.x * QB + wv * (32 * NC);
+    v4i B[NC][8];
+    int pq[NC];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int qi = q0 + 32 * c + col;
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (qi < nq) { lo = qp[2 * qi]; hi = qp[2 * qi + 1]; }
+    for (int c = 0; c < NC; c++) {
+        const int qi = min(q0 + 32 * c + col, nq - 1);      // rows past the end repeat the last query, never stored
+        const uint4 lo = qp[2 * qi], hi = qp[2 * qi + 1];
         const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         int pc = 0;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             pc += __popc(dw[s]);
-            B[c][s] = widen16((dw[s] >> (16 * hh)) & 0xFFFFu);
+            B[c][s] = widen_query16<WIDE>((dw[s] >> (16 * hh)) & 0xFFFFu);
         }
         pq[c] = pc;
     }
 
-    // staging of one train tile: thread -> (train r, dword s) x 2, plus threads 0..63 -> base key of train tid
-    auto load_tile = [&](int it, StageRegs& R) {
-        const int t0 = it * kTT;
-        const int r0 = tid >> 3, r1 = r0 + 32;
-        R.d0 = (t0 + r0 < nt) ? tw[(int64_t)(t0 + r0) * 8 + (tid & 7)] : 0u;
-        R.d1 = (t0 + r1 < nt) ? tw[(int64_t)(t0 + r1) * 8 + (tid & 7)] : 0u;
-        if (tid < kTT) {
-            R.a = make_uint4(0, 0, 0, 0); R.b = R.a;
-            if (t0 + tid < nt) { R.a = tp[2 * (int64_t)(t0 + tid)]; R.b = tp[2 * (int64_t)(t0 + tid) + 1]; }
-        }
+    // staging of one train tile of TT trains: thread -> (train r + 32 k, dword s), k < TT/32; rows past the end repeat
+    // the last train (their accumulator preload kNone keeps them out of every top-2). The 8 lanes of a train add up
+    // its popcount (DPP) and all store the same preload word. No branches: the tile after the last is staged too,
+    // clamped.
+    constexpr int NR = TT / 32;
+    const int sr = tid >> 3, ss = tid & 7;
+    uint32_t dreg[NR];
+    auto load_tile = [&](int it) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) dreg[k] = tw[(int64_t)min(it * TT + sr + 32 * k, nt - 1) * 8 + ss];
     };
-    auto store_tile = [&](int it, int buf, const StageRegs& R) {
-        const int t0 = it * kTT;
-        const int r0 = tid >> 3, r1 = r0 + 32, s = tid & 7;
-        v4i* p0 = reinterpret_cast<v4i*>(&s_a[buf][r0 * kRowB + s * 32]);
-        p0[0] = widen16(R.d0 & 0xFFFFu);
-        p0[1] = widen16(R.d0 >> 16);
-        v4i* p1 = reinterpret_cast<v4i*>(&s_a[buf][r1 * kRowB + s * 32]);
-        p1[0] = widen16(R.d1 & 0xFFFFu);
-        p1[1] = widen16(R.d1 >> 16);
-        if (tid < kTT) {
-            const int pc = __popc(R.a.x) + __popc(R.a.y) + __popc(R.a.z) + __popc(R.a.w) +
-                           __popc(R.b.x) + __popc(R.b.y) + __popc(R.b.z) + __popc(R.b.w);
-            s_base[buf][tid] = (t0 + tid < nt) ? ((pc << 16) | (t0 + tid)) : kNone;
+    auto store_tile = [&](int it, int buf) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            v4i* p = reinterpret_cast<v4i*>(&s_a[buf][(sr + 32 * k) * kRowB + ss * 32]);
+            p[0] = widen_train16<WIDE>(dreg[k] & 0xFFFFu);
+            p[1] = widen_train16<WIDE>(dreg[k] >> 16);
+            const int pt = sum8(__popc(dreg[k])), tt = it * TT + sr + 32 * k;
+            s_base[buf][sr + 32 * k] = tt < nt ? (WIDE ? (((pt + 256) << 16) | tt) : ((pt + 256) << 12) + tt) + kKeyBias : kNone;
         }
     };
 
-    // running (best, runner-up) of key' = ((popcount(t) - 2 <q,t>) << 16) + train index, per column tile; popcount(q)
-    // is the same for every train of a query and is added at the end
-    int m1[2] = {kNone, kNone}, m2[2] = {kNone, kNone};
-    const int kMinus2 = -131072;      // -2 << 16
+    // running (best, runner-up) per column tile, two independent chains (even / odd accumulator registers)
+    float m1[NC][2], m2[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) { m1[c][p] = __int_as_float(0x7F7FFFFF); m2[c][p] = __int_as_float(0x7F7FFFFF); }
 
-    const int ntiles = (nt + kTT - 1) / kTT;
-    StageRegs R;
-    if (ntiles > 0) { load_tile(0, R); store_tile(0, 0, R); }
+    const int ntiles = (nt + TT - 1) / TT;
+    if (ntiles > 0) { load_tile(0); store_tile(0, 0); }
     __syncthreads();
     for (int it = 0; it < ntiles; it++) {
         const int buf = it & 1;
-        const bool more = it + 1 < ntiles;
-        if (more) load_tile(it + 1, R);
+        load_tile(it + 1);
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++) {
+        for (int rt = 0; rt < NR; rt++) {
             const uint8_t* arow = &s_a[buf][(rt * 32 + col) * kRowB + hh * 16];
             v4i A[8];
 #pragma unroll
             for (int s = 0; s < 8; s++) A[s] = *reinterpret_cast<const v4i*>(arow + s * 32);
-            // accumulator register j of this lane is train row (j & 3) + 8 (j >> 2) + 4 hh of the tile
-            v4i bs[4];
+            // preload of accumulator register j of this lane = train row (j & 3) + 8 (j >> 2) + 4 hh of the row tile
+            v16i bs;
 #pragma unroll
-            for (int g = 0; g < 4; g++) bs[g] = *reinterpret_cast<const v4i*>(&s_base[buf][rt * 32 + 8 * g + 4 * hh]);
+            for (int g = 0; g < 4; g++) {
+                const v4i b4 = *reinterpret_cast<const v4i*>(&s_base[buf][rt * 32 + 8 * g + 4 * hh]);
+                bs[4 * g] = b4.x; bs[4 * g + 1] = b4.y; bs[4 * g + 2] = b4.z; bs[4 * g + 3] = b4.w;
+            }
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                v16i acc = {};
+            for (int cp = 0; cp < NC; cp += 2) {
+                v16i acc0 = {}, acc1 = {};
+                if (!WIDE) { acc0 = bs; acc1 = bs; }
 #pragma unroll
-                for (int s = 0; s < 8; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s], B[c][s], acc, 0, 0, 0);
+                for (int s = 0; s < 8; s++) {
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s], B[cp][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s], B[cp + 1][s], acc1, 0, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    const int key = mad_i24(acc[j], kMinus2, bs[j >> 2][j & 3]);
-                    m2[c] = med3_i32(m1[c], m2[c], key);
-                    m1[c] = min(m1[c], key);
+                    top2_update(m1[cp][j & 1], m2[cp][j & 1], WIDE ? (acc0[j] << 10) + bs[j] : acc0[j]);
+                    top2_update(m1[cp + 1][j & 1], m2[cp + 1][j & 1], WIDE ? (acc1[j] << 10) + bs[j] : acc1[j]);
                 }
             }
         }
-        if (more) store_tile(it + 1, buf ^ 1, R);
+        store_tile(it + 1, buf ^ 1);
         __syncthreads();
     }
 
-    // lanes l and l ^ 32 hold the same query over disjoint trains
-    uint32_t k0[2], k1[2];
+    // merge the two chains of a column tile, then lanes l and l ^ 32 (same query, disjoint trains); plain integer
+    // compares from here on
+    uint32_t k0[NC], k1[NC];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int p1 = __shfl_xor(m1[c], 32), p2 = __shfl_xor(m2[c], 32);
-        const int n1 = min(m1[c], p1);
-        const int n2 = min(max(m1[c], p1), min(m2[c], p2));
-        k0[c] = n1 == kNone ? 0xFFFFFFFFu : (((uint32_t)((n1 >> 16) + pq[c]) << 16) | ((uint32_t)n1 & 0xFFFFu));
-        k1[c] = n2 == kNone ? 0xFFFFFFFFu : (((uint32_t)((n2 >> 16) + pq[c]) << 16) | ((uint32_t)n2 & 0xFFFFu));
+    for (int c = 0; c < NC; c++) {
+        const int x1 = __float_as_int(m1[c][0]), x2 = __float_as_int(m2[c][0]);
+        const int y1 = __float_as_int(m1[c][1]), y2 = __float_as_int(m2[c][1]);
+        const int a1 = min(x1, y1);
+        const int a2 = min(max(x1, y1), min(x2, y2));
+        const int p1 = __shfl_xor(a1, 32), p2 = __shfl_xor(a2, 32);
+        k0[c] = final_key<WIDE>(min(a1, p1), pq[c]);
+        k1[c] = final_key<WIDE>(min(max(a1, p1), min(a2, p2)), pq[c]);
     }
     if (MODE == 0) {
         if (hh == 0) {
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < NC; c++) {
                 const int qi = q0 + 32 * c + col;
                 if (qi < nq) keys[(int64_t)pair * maxq + qi] = make_uint2(k0[c], k1[c]);
             }
@@ -185,7 +229,7 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
         __syncthreads();
         int n_ok = 0;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < NC; c++) {
             const int qi = q0 + 32 * c + col;
             bool ok = false;
             if (hh == 0 && qi < nq && k1[c] != 0xFFFFFFFFu)
@@ -198,17 +242,47 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
     }
 }
 
+// Two waves per SIMD in both shapes (<= 256 VGPRs; the 512-query shape holds 128 VGPRs of query fragments per wave).
+template <int MODE, bool WIDE, int NC, int TT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_knn2_mfma(
+    const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, const uint8_t* __restrict__ t,
+    const int* __restrict__ nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* __restrict__ keys, int maxq,
+    double ratio, int* __restrict__ good) {
+    knn2_body<MODE, WIDE, NC, TT>(q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride, keys, maxq, ratio, good);
+}
+
+template <int MODE, bool WIDE, int NC, int TT>
+void launch_one(int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed, const uint8_t* t,
+                const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* keys, int maxq, double ratio,
+                int* good) {
+    const dim3 grid((unsigned)((nq_max + 128 * NC - 1) / (128 * NC)), (unsigned)n_pairs);
+    hipLaunchKernelGGL((k_knn2_mfma<MODE, WIDE, NC, TT>), grid, dim3(256), 0, st, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed,
+                       q_stride, t_stride, keys, maxq, ratio, good);
+}
+
 }  // namespace
 
-void launch_knn2_mfma(int mode, dim3 grid, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
+void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
                       const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
-                      uint2* keys, int maxq, double ratio, int* good) {
-    if (mode == 0)
-        hipLaunchKernelGGL(k_knn2_mfma<0>, grid, dim3(256), 0, st, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
-                           t_stride, keys, maxq, ratio, good);
-    else
-        hipLaunchKernelGGL(k_knn2_mfma<1>, grid, dim3(256), 0, st, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
-                           t_stride, keys, maxq, ratio, good);
+                      uint2* keys, int maxq, double ratio, int* good, int max_train) {
+    if (nq_max <= 0 || n_pairs <= 0) return;
+    static const int force_nc = [] { const char* e = getenv("ARIA_KNN_NC"); return e ? atoi(e) : 0; }();
+    const bool wide = max_train > kNarrowMax;      // only built in the 256-query form
+    // 512-query workgroups amortise the train staging and the A-fragment reads over twice the MFMAs, but need enough
+    // workgroups to fill 256 CUs x 2; small jobs (a single frame pair) take the 256-query form
+    const int64_t blocks4 = (int64_t)((nq_max + 511) / 512) * n_pairs;
+    const bool nc4 = !wide && (force_nc ? force_nc == 4 : blocks4 >= 1024);
+#define ARIA_KNN_ARGS nq_max, n_pairs, st, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride, keys, maxq, ratio, good
+    if (mode == 0) {
+        if (wide) launch_one<0, true, 2, 64>(ARIA_KNN_ARGS);
+        else if (nc4) launch_one<0, false, 4, 64>(ARIA_KNN_ARGS);
+        else launch_one<0, false, 2, 64>(ARIA_KNN_ARGS);
+    } else {
+        if (wide) launch_one<1, true, 2, 64>(ARIA_KNN_ARGS);
+        else if (nc4) launch_one<1, false, 4, 64>(ARIA_KNN_ARGS);
+        else launch_one<1, false, 2, 64>(ARIA_KNN_ARGS);
+    }
+#undef ARIA_KNN_ARGS
 }
 
 }  // namespace aria

@@ -238,20 +238,23 @@ struct aria_matcher_s {
 
 namespace {
 
-// kNN-2 of every (query block, pair): matrix-core kernel (knn2_mfma.hip) unless the handle asks for the VALU one
-void launch_knn2(aria_matcher_s* m, int mode, dim3 grid, const uint8_t* q, const int* nq_arr, int nq_fixed,
+// kNN-2 of n_pairs pairs of at most nq_max queries: matrix-core kernel (knn2_mfma.hip) unless the handle asks for the
+// VALU one
+void launch_knn2(aria_matcher_s* m, int mode, int nq_max, int n_pairs, const uint8_t* q, const int* nq_arr, int nq_fixed,
                  const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* keys,
-                 int maxq, double ratio, int* good) {
+                 int maxq, double ratio, int* good, int max_train) {
     if (!m->knn_valu) {
-        launch_knn2_mfma(mode, grid, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride, keys, maxq,
-                         ratio, good);
-    } else if (mode == 0) {
+        launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
+                         keys, maxq, ratio, good, max_train);
+        return;
+    }
+    const dim3 grid((unsigned)((nq_max + 255) / 256), (unsigned)n_pairs);
+    if (mode == 0)
         hipLaunchKernelGGL(k_knn2<0>, grid, dim3(256), 0, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
                            t_stride, keys, maxq, ratio, good);
-    } else {
+    else
         hipLaunchKernelGGL(k_knn2<1>, grid, dim3(256), 0, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
                            t_stride, keys, maxq, ratio, good);
-    }
 }
 
 int ensure_keys(aria_matcher_s* m, size_t entries) {
@@ -393,8 +396,8 @@ int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t
     ARIA_HIP(hipSetDevice(m->device));
     int rc = upload_pair(m, q, nq, t, nt);
     if (rc != ARIA_OK) return rc;
-    launch_knn2(m, 0, dim3((nq + 255) / 256, 1), m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
-                m->max_query, 0.0, nullptr);
+    launch_knn2(m, 0, nq, 1, m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
+                m->max_query, 0.0, nullptr, nt);
     hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
                        m->d_m, m->d_n, m->max_query, m->d_err);
     ARIA_HIP(hipGetLastError());
@@ -419,8 +422,8 @@ int aria_matcher_knn2(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t*
     ARIA_HIP(hipSetDevice(m->device));
     int rc = upload_pair(m, q, nq, t ? t : q, nt);
     if (rc != ARIA_OK) return rc;
-    launch_knn2(m, 0, dim3((nq + 255) / 256, 1), m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
-                m->max_query, 0.0, nullptr);
+    launch_knn2(m, 0, nq, 1, m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
+                m->max_query, 0.0, nullptr, nt);
     hipLaunchKernelGGL(k_unpack_knn, dim3((nq + 255) / 256), dim3(256), 0, m->stream, m->d_keys, nq, m->d_idx,
                        m->d_idx + 2 * (size_t)m->max_query);
     ARIA_HIP(hipGetLastError());
@@ -451,8 +454,8 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
         hipStreamSynchronize(m->stream);
         hipEventRecord(ev.e[0], m->stream);
     }
-    launch_knn2(m, 0, dim3((unsigned)((maxq + 255) / 256), n_pairs), d_query, d_nq, 0, d_train, d_nt, 0, desc_stride,
-                desc_stride, m->d_keys, (int)maxq, 0.0, nullptr);
+    launch_knn2(m, 0, (int)maxq, n_pairs, d_query, d_nq, 0, d_train, d_nt, 0, desc_stride,
+                desc_stride, m->d_keys, (int)maxq, 0.0, nullptr, (int)maxq);
     if (m->prof_enabled) {
         hipEventRecord(ev.e[1], m->stream);
         hipStreamSynchronize(m->stream);
@@ -474,8 +477,8 @@ int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int n
     ARIA_HIP(hipSetDevice(m->device));
     ARIA_HIP(hipMemsetAsync(d_good, 0, sizeof(int) * (size_t)n_kf, m->stream));
     if (nq == 0) return ARIA_OK;
-    launch_knn2(m, 1, dim3((nq + 255) / 256, n_kf), d_query, nullptr, nq, d_db, d_kf_counts, 0, (int64_t)0, desc_stride,
-                nullptr, 0, ratio, d_good);
+    launch_knn2(m, 1, nq, n_kf, d_query, nullptr, nq, d_db, d_kf_counts, 0, (int64_t)0, desc_stride,
+                nullptr, 0, ratio, d_good, (int)(desc_stride / 32));
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

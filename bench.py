@@ -232,8 +232,14 @@ def main():
                                 "achieved_GBs": round(b_extract * prof_frames / (ext_ms * 1e-3) / 1e9, 1) if ext_ms else None,
                                 "frac": round(b_extract * prof_frames / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_ms else None},
             "stage_us_per_frame": {k: round(1e3 * stage_ms[k] / max(prof_frames, 1), 3) for k in stage_ms},
-            "matcher_popcount_dwords_per_s": round(8.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))
-                                                   * args.steps / (stage_ms["knn2"] * 1e-3), 1) if stage_ms["knn2"] else None,
+            # kNN-2 runs on the matrix cores (knn2_mfma.hip): exact int8 inner products of bit-widened descriptors.
+            # ops = 2 * 256 * sum(nq * nt) per launch; peak = 2 x the dense bf16 MFMA peak (MI355X_MICROARCH.md, I8 row)
+            "matcher": {"kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8 + per-lane top-2)", "bound": "mfma",
+                        "achieved": round(512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))
+                                          * args.steps / (stage_ms["knn2"] * 1e-3) / 1e12, 1) if stage_ms["knn2"] else None,
+                        "peak": 5000.0, "unit": "TOP/s",
+                        "frac": round(512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))
+                                      * args.steps / (stage_ms["knn2"] * 1e-3) / 1e12 / 5000.0, 4) if stage_ms["knn2"] else None},
         }
         out = {
             "metric": "frames/s ORB extract+BF-match, 640x480 @2000 kp" if (W, H, NF) == (640, 480, 2000)

@@ -30,3 +30,17 @@ def test_variant_matches_golden(env):
                          text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("OK") == 3
+
+
+@pytest.mark.parametrize("env", [{}, {"ARIA_KNN_NC": "2"}, {"ARIA_KNN_NC": "4"}, {"ARIA_KNN_IMPL": "valu"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_knn2_kernels_against_brute_force(env):
+    """Matrix-core kNN-2 in both workgroup shapes (256 / 512 queries), both key layouts (train sets above 4096
+    descriptors take the 16-bit-index one) and the vector-ALU kernel, through the host, batched-device and
+    keyframe-DB entry points, against a numpy brute force."""
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_check.py")], env=e, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bad" not in out.stdout
