@@ -851,14 +851,20 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     const uint8_t* ctr = s_raw[wv * 4 + grp] + kHalfPatch * kIcPitch + (x - xr);
     constexpr int umax[16] = ARIA_UMAX_LIST;
     const int ua = 2 * l16 - kHalfPatch, ub = ua + 1;      // ub == 16 for the last lane: outside every row
-    int m10 = 0, m01 = 0;
+    // Branch-free: a sample outside the disc is read (it is inside the staged window) and selected to 0. Column sums
+    // first -- m10 = ua * sum_v I(ua, v) + ub * sum_v I(ub, v) -- so a row costs two selects, three adds and one mad.
+    int sa = 0, sb = 0, m01 = 0;
 #pragma unroll
     for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
         const int d = umax[v < 0 ? -v : v];
         const uint8_t* rowp = ctr + v * kIcPitch;
-        if (abs(ua) <= d) { const int val = rowp[ua]; m10 += ua * val; m01 += v * val; }
-        if (abs(ub) <= d) { const int val = rowp[ub]; m10 += ub * val; m01 += v * val; }
+        const int va = (abs(ua) <= d) ? (int)rowp[ua] : 0;
+        const int vb = (abs(ub) <= d) ? (int)rowp[ub] : 0;
+        sa += va;
+        sb += vb;
+        m01 += v * (va + vb);
     }
+    int m10 = ua * sa + ub * sb;
     m10 = row16_sum(m10);
     m01 = row16_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -871,15 +877,29 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     const float a = (float)cd, b = (float)sd;
     const uint8_t* bc = s_patch[wv * 4 + grp] + kDescR * kDescPitch + (x - xs);     // window address of the keypoint centre
     __builtin_amdgcn_wave_barrier();
+    // Both samples of a test ride in one register pair: (fx0, fx1) = (px0, px1) * a + (py0, py1) * (-b) and
+    // (fy0, fy1) = (px0, px1) * b + (py0, py1) * a -- packed multiplies and adds, each rounded once like the
+    // reference's px*a - py*b / px*b + py*a (no FMA). cvRound is round-half-even = adding 1.5 * 2^23 in
+    // the default rounding mode: the integer lands in the low mantissa bits, so the window address is one 24-bit mad
+    // of the raw float bits plus a constant.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 aa = {a, a}, bb = {b, b}, nbb = {-b, -b};
+    const f2 magic = {12582912.0f, 12582912.0f};
+    constexpr uint32_t kMagicBits = 0x4B400000u;          // bits of 1.5 * 2^23
+    // mad_u24(by, pitch, bx) = ((by & 0xFFFFFF) * pitch) + bx = (0x400000 + iy) * pitch + kMagicBits + ix
+    const uint8_t* bc0 = bc - (size_t)(0x400000u * (uint32_t)kDescPitch + kMagicBits);
     uint32_t mine = 0;
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const float px0 = (float)(signed char)(pat[it] & 0xFF), py0 = (float)(signed char)((pat[it] >> 8) & 0xFF);
         const float px1 = (float)(signed char)((pat[it] >> 16) & 0xFF), py1 = (float)(signed char)((pat[it] >> 24) & 0xFF);
-        const float fx0 = px0 * a - py0 * b, fy0 = px0 * b + py0 * a;
-        const float fx1 = px1 * a - py1 * b, fy1 = px1 * b + py1 * a;
-        const int t0 = bc[(int)rintf(fy0) * kDescPitch + (int)rintf(fx0)];
-        const int t1 = bc[(int)rintf(fy1) * kDescPitch + (int)rintf(fx1)];
+        const f2 PX = {px0, px1}, PY = {py0, py1};
+        const f2 fx = PX * aa + PY * nbb + magic;
+        const f2 fy = PX * bb + PY * aa + magic;
+        const uint32_t o0 = __umul24(__float_as_uint(fy.x), kDescPitch) + __float_as_uint(fx.x);
+        const uint32_t o1 = __umul24(__float_as_uint(fy.y), kDescPitch) + __float_as_uint(fx.y);
+        const int t0 = bc0[o0];
+        const int t1 = bc0[o1];
         const unsigned long long m = __ballot(t0 < t1);
         if (l16 == it) mine = (uint32_t)(m >> (16 * grp)) & 0xFFFFu;
     }
