@@ -733,15 +733,14 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// The rotated pattern never leaves [-18, 18]^2 (|x|,|y| <= 13*sqrt(2)), so a 37-row x 44-byte window of the blurred
+// The rotated pattern never leaves [-18, 18]^2 (|x|,|y| <= 13*sqrt(2)), so a 37-row x 40-byte window of the blurred
 // level (dword-aligned start) holds every sample of a keypoint.
 constexpr int kDescR = 18;
 constexpr int kDescRows = 2 * kDescR + 1;   // 37
-constexpr int kDescPitch = 44;              // 11 dwords >= 37 + 3 bytes of alignment slack
-constexpr int kDescDwords = kDescRows * 11; // 407
+constexpr int kDescPitch = 48;              // LDS pitch; 40 bytes (5 dword pairs >= 37 + 3 bytes of alignment slack) are staged
 constexpr int kDescKp = 8;                  // keypoints per 128-thread workgroup: 2 waves x 4 DPP rows
-constexpr int kIcPitch = 36;                // raw window: 31 rows x 9 dwords (31 + 3 bytes of alignment slack)
-constexpr int kIcDwords = 31 * 9;           // 279
+constexpr int kIcPitch = 40;                // raw window: 31 rows x 5 dword pairs (>= 31 + 3 bytes of alignment slack)
+struct __attribute__((packed, aligned(4))) DwordPair { uint32_t lo, hi; };   // 8-byte load from a 4-byte-aligned address
 
 // sum over the 16 lanes of a DPP row (every lane of the row gets the total)
 __device__ __forceinline__ int row16_sum(int v) {
@@ -783,6 +782,7 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     }
     if (slot0 == 0 && lane == 0) counts[frame] = min(total, kp_cap);
     if (slot0 >= P.sel_frame_entries) return;
+    l = __builtin_amdgcn_readfirstlane(l);     // the wave's four slots are in one level: keep the level geometry scalar
     const LevelGeom g = P.lv[l];
     const int i0 = slot0 - g.sel_off;
     const int nk = min(4, cnt[l] - i0);                                // valid keypoints of this wave
@@ -799,50 +799,56 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
 #pragma unroll
     for (int it = 0; it < 16; it++) pat[it] = *reinterpret_cast<const int*>(&kPattern31[(it * 16 + l16) * 4]);
 
-    // ---- stage the blurred 37 x 44 window of each keypoint in LDS (overlaps the moment gathers) ----
+    // ---- stage the blurred 37 x 40 and the raw 31 x 40 window of each keypoint in LDS: 8-byte loads, lane ->
+    //      (row mod 3, dword pair), so 15 lanes fetch three whole rows per instruction and the next address is one add.
+    //      No lane is ever masked: lane 15 (rr == 3) and the lanes past the last row repeat a (row, pair) that another
+    //      lane or step also writes -- same address, same data. (The windows end <= 22 px right of the keypoint,
+    //      which is >= 31 px inside the level.) ----
     const uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
-    const int xs = (x - kDescR) & ~3;                      // dword-aligned first column (keypoints are >= 31 px inside)
-    uint32_t* sp = reinterpret_cast<uint32_t*>(s_patch[wv * 4 + grp]);
-    for (int k0 = 0; k0 < 26; k0 += 13) {
-        uint32_t pv[13];
+    const int xs = (x - kDescR) & ~3;                      // dword-aligned first column
+    const int rr = l16 / 5, cc = l16 - 5 * rr;
+    {
+        uint8_t* sp = s_patch[wv * 4 + grp] + 8 * cc;
+        const uint8_t* gp = bl + (int64_t)(y - kDescR) * g.pitch + xs + 8 * cc;
+        const int64_t p64 = g.pitch;
+        const uint8_t* gpl = gp + rr * p64;                  // lane part once; the step offsets below are wave-uniform
+        DwordPair pv[13];
+#pragma unroll
+        for (int k = 0; k < 13; k++)                          // step 12: row 36 for every lane
+            pv[k] = *reinterpret_cast<const DwordPair*>((3 * k + 3 < kDescRows) ? gpl + 3 * k * p64 : gp + (kDescRows - 1) * p64);
 #pragma unroll
         for (int k = 0; k < 13; k++) {
-            const int d = l16 + 16 * (k0 + k);              // dword index in the window, row-major, 11 per row
-            const int r = d / 11, c = d - r * 11;
-            pv[k] = (d < kDescDwords) ? *reinterpret_cast<const uint32_t*>(bl + (int64_t)(y - kDescR + r) * g.pitch + xs + 4 * c) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 13; k++) {
-            const int d = l16 + 16 * (k0 + k);
-            if (d < kDescDwords) sp[d] = pv[k];
+            const int row = (3 * k + 3 < kDescRows) ? 3 * k + rr : kDescRows - 1;
+            *reinterpret_cast<uint2*>(sp + row * kDescPitch) = make_uint2(pv[k].lo, pv[k].hi);
         }
     }
-
-    // ---- stage the raw 31 x 36 window too: coalesced dword loads instead of 62 scattered byte gathers per lane
-    //      (the texture path, not HBM or the VALU, was what bounded this kernel) ----
     int pitch;
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
     const int xr = (x - kHalfPatch) & ~3;
-    const bool raw_dword = (l > 0) || S.aligned4;
-    uint32_t* sr = reinterpret_cast<uint32_t*>(s_raw[wv * 4 + grp]);
-    for (int k0 = 0; k0 < 18; k0 += 9) {
-        uint32_t rv[9];
+    // a caller's level-0 image may be byte-aligned only (the level is the same for the wave's four keypoints)
+    const bool raw_dword = __builtin_amdgcn_readfirstlane((l > 0) || S.aligned4) != 0;
+    {
+        uint8_t* sr = s_raw[wv * 4 + grp] + 8 * cc;
+        const uint8_t* gp = img + (int64_t)(y - kHalfPatch) * pitch + xr + 8 * cc;
+        const int64_t p64 = pitch;
+        const uint8_t* gpl = gp + rr * p64;
+        DwordPair rv[11];
+        if (raw_dword) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int d = l16 + 16 * (k0 + k);              // dword index in the raw window, 9 per row
-            const int r = d / 9, c = d - r * 9;
-            const uint8_t* q = img + (int64_t)(y - kHalfPatch + r) * pitch + xr + 4 * c;
-            uint32_t v = 0;
-            if (d < kIcDwords) {
-                if (raw_dword) v = *reinterpret_cast<const uint32_t*>(q);
-                else v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            for (int k = 0; k < 11; k++)                      // step 10: row 30 for every lane
+                rv[k] = *reinterpret_cast<const DwordPair*>((3 * k + 3 < 31) ? gpl + 3 * k * p64 : gp + 30 * p64);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const uint8_t* q = (3 * k + 3 < 31) ? gpl + 3 * k * p64 : gp + 30 * p64;
+                rv[k].lo = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                rv[k].hi = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
             }
-            rv[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int d = l16 + 16 * (k0 + k);
-            if (d < kIcDwords) sr[d] = rv[k];
+        for (int k = 0; k < 11; k++) {
+            const int row = (3 * k + 3 < 31) ? 3 * k + rr : 30;
+            *reinterpret_cast<uint2*>(sr + row * kIcPitch) = make_uint2(rv[k].lo, rv[k].hi);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -858,8 +864,11 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
         const int d = umax[v < 0 ? -v : v];
         const uint8_t* rowp = ctr + v * kIcPitch;
-        const int va = (abs(ua) <= d) ? (int)rowp[ua] : 0;
-        const int vb = (abs(ub) <= d) ? (int)rowp[ub] : 0;
+        // volatile: keep the two LDS reads unconditional (otherwise each one is wrapped in an exec-mask branch)
+        typedef const volatile __attribute__((address_space(3))) uint8_t* lds_vptr;
+        const int ra = *(lds_vptr)(rowp + ua), rb = *(lds_vptr)(rowp + ub);
+        const int va = (abs(ua) <= d) ? ra : 0;
+        const int vb = (abs(ub) <= d) ? rb : 0;
         sa += va;
         sb += vb;
         m01 += v * (va + vb);
