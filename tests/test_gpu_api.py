@@ -185,6 +185,42 @@ def test_batch_device_equals_per_frame_and_chunks(aria, torch_cuda):
         e.close()
 
 
+@pytest.mark.parametrize("off,row_stride", [(1, 643), (2, 642), (4, 644), (3, 640)])
+def test_batch_device_byte_aligned_images(aria, torch_cuda, off, row_stride):
+    """Resident images that are only byte-aligned (odd base address and/or odd row stride) take the per-byte load
+    paths of every kernel that reads level 0; results must equal the aligned host-buffer path."""
+    torch = torch_cuda
+    W, H, NF, B = 640, 480, 1000, 3
+    seq = aria.synth_sequence(31, 2, W, H)[:B]
+    dev = torch.device("cuda", 0)
+    frame_stride = row_stride * H + 5
+    buf = np.zeros(off + B * frame_stride + 64, np.uint8)
+    for i in range(B):
+        v = buf[off + i * frame_stride: off + i * frame_stride + row_stride * H].reshape(H, row_stride)
+        v[:, :W] = seq[i]
+    d_buf = torch.from_numpy(buf).to(dev)
+    single = _ext(aria, nf=NF)
+    per_frame = [single.extract(seq[i]) for i in range(B)]
+    single.close()
+    e = aria.OrbHipExtractor(max_features=NF, max_width=W, max_height=H, max_batch=2)
+    try:
+        cap = e.kp_capacity()
+        kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.extract_batch_device(d_buf.data_ptr() + off, B, W, H, kps, desc, counts, cap, frame_stride=frame_stride,
+                               row_stride=row_stride)
+        e.check()
+        c, k, d = counts.cpu().numpy(), kps.cpu().numpy(), desc.cpu().numpy()
+        for i in range(B):
+            assert c[i] == len(per_frame[i]["keypoints"])
+            assert k[i, :c[i]].tobytes() == per_frame[i]["keypoints"].tobytes()
+            assert np.array_equal(d[i, :c[i]], per_frame[i]["descriptors"])
+    finally:
+        e.close()
+
+
 def test_batch_kp_cap_too_small_is_reported(aria, torch_cuda):
     torch = torch_cuda
     seq = aria.synth_sequence(1, 1, 640, 480)
