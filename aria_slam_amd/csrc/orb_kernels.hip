@@ -25,9 +25,24 @@
 
 namespace aria {
 
-__device__ __attribute__((aligned(16))) const signed char kPattern31[1024] = {
+// The rBRIEF pattern, 4 signed bytes (x0, y0, x1, y1) per test, laid out for k_describe: lane l16 evaluates tests
+// 16*it + l16, it = 0..15, and fetches its 16 dwords with four 16-byte loads (the texture-address path charges per
+// instruction, not per byte): word [l16][it] = test 16*it + l16.
+struct PatternLaneMajor { uint32_t w[16][16]; };
+constexpr PatternLaneMajor make_pattern_lane_major() {
+    constexpr int src[1024] = {
 #include "orb_pattern_31.inc"
-};
+    };
+    PatternLaneMajor p{};
+    for (int l = 0; l < 16; l++)
+        for (int it = 0; it < 16; it++) {
+            const int t = 16 * it + l;
+            p.w[l][it] = ((uint32_t)(src[4 * t] & 0xFF)) | ((uint32_t)(src[4 * t + 1] & 0xFF) << 8) |
+                         ((uint32_t)(src[4 * t + 2] & 0xFF) << 16) | ((uint32_t)(src[4 * t + 3] & 0xFF) << 24);
+        }
+    return p;
+}
+__device__ __attribute__((aligned(16))) const PatternLaneMajor kPattern31 = make_pattern_lane_major();
 
 // end-of-row table of the radius-15 disc (orb.cpp computeKeyPoints umax; verified against the host
 // computation in tests/test_host_logic.py)
@@ -733,14 +748,14 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// The rotated pattern never leaves [-18, 18]^2 (|x|,|y| <= 13*sqrt(2)), so a 37-row x 40-byte window of the blurred
+// The rotated pattern never leaves [-18, 18]^2 (|x|,|y| <= 13*sqrt(2)), so a 37-row x 48-byte window of the blurred
 // level (dword-aligned start) holds every sample of a keypoint.
 constexpr int kDescR = 18;
 constexpr int kDescRows = 2 * kDescR + 1;   // 37
-constexpr int kDescPitch = 48;              // LDS pitch; 40 bytes (5 dword pairs >= 37 + 3 bytes of alignment slack) are staged
+constexpr int kDescPitch = 48;              // three 16-byte pieces per row (>= 37 + 3 bytes of alignment slack)
 constexpr int kDescKp = 8;                  // keypoints per 128-thread workgroup: 2 waves x 4 DPP rows
-constexpr int kIcPitch = 40;                // raw window: 31 rows x 5 dword pairs (>= 31 + 3 bytes of alignment slack)
-struct __attribute__((packed, aligned(4))) DwordPair { uint32_t lo, hi; };   // 8-byte load from a 4-byte-aligned address
+constexpr int kIcPitch = 48;                // raw window: 31 rows x three 16-byte pieces (>= 31 + 3 bytes of alignment slack)
+struct __attribute__((packed, aligned(4))) DwordQuad { uint32_t a, b, c, d; };   // 16-byte load from a 4-byte-aligned address
 
 // sum over the 16 lanes of a DPP row (every lane of the row gets the total)
 __device__ __forceinline__ int row16_sum(int v) {
@@ -761,7 +776,11 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
                                                   const uint8_t* __restrict__ blur, const uint2* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
-                                                  int* __restrict__ err, int n_frames, int blocks_per_frame) {
+                                                  int* __restrict__ err, int n_frames, int blocks_per_frame,
+                                                  unsigned long long* __restrict__ stamps) {
+    // diagnostic only (ARIA_DESC_STAMPS=1): s_memtime at the phase boundaries of every wave
+#define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    DSTAMP(0);
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[kDescKp][kDescRows * kDescPitch];
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[kDescKp][31 * kIcPitch];
     // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
@@ -793,33 +812,40 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     if (valid && !fits && l16 == 0) atomicOr(err, ERRBIT_KPCAP);
     const uint2 sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
     const int x = sv.x & 0xFFFF, y = sv.x >> 16;
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    DSTAMP(1);
 
     // pattern rows of this lane (independent of the keypoint): issue early
     int pat[16];
 #pragma unroll
-    for (int it = 0; it < 16; it++) pat[it] = *reinterpret_cast<const int*>(&kPattern31[(it * 16 + l16) * 4]);
+    for (int it = 0; it < 16; it += 4) {
+        const uint4 p4 = *reinterpret_cast<const uint4*>(&kPattern31.w[l16][it]);
+        pat[it] = (int)p4.x; pat[it + 1] = (int)p4.y; pat[it + 2] = (int)p4.z; pat[it + 3] = (int)p4.w;
+    }
 
-    // ---- stage the blurred 37 x 40 and the raw 31 x 40 window of each keypoint in LDS: 8-byte loads, lane ->
-    //      (row mod 3, dword pair), so 15 lanes fetch three whole rows per instruction and the next address is one add.
-    //      No lane is ever masked: lane 15 (rr == 3) and the lanes past the last row repeat a (row, pair) that another
-    //      lane or step also writes -- same address, same data. (The windows end <= 22 px right of the keypoint,
-    //      which is >= 31 px inside the level.) ----
+    // ---- stage the blurred 37 x 48 and the raw 31 x 48 window of each keypoint in LDS. The texture-address path, not
+    //      bandwidth, bounds this kernel (TA busy 75-80 % with 8-byte loads), and it charges per instruction: so 16-byte
+    //      loads, lane -> (row mod 5, 16-byte piece): 15 lanes fetch five whole rows per instruction, the next address
+    //      is one add, and no lane is ever masked -- lane 15 (rr == 5) and the lanes past the last row repeat a
+    //      (row, piece) that another lane or step also writes: same address, same data. The 48 bytes end <= 33 px
+    //      right of a keypoint that is >= 31 px inside the level, on rows >= 16 above the last: never past the image. ----
     const uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
     const int xs = (x - kDescR) & ~3;                      // dword-aligned first column
-    const int rr = l16 / 5, cc = l16 - 5 * rr;
+    const int rr = l16 / 3, cc = l16 - 3 * rr;
     {
-        uint8_t* sp = s_patch[wv * 4 + grp] + 8 * cc;
-        const uint8_t* gp = bl + (int64_t)(y - kDescR) * g.pitch + xs + 8 * cc;
+        uint8_t* sp = s_patch[wv * 4 + grp] + 16 * cc;
         const int64_t p64 = g.pitch;
-        const uint8_t* gpl = gp + rr * p64;                  // lane part once; the step offsets below are wave-uniform
-        DwordPair pv[13];
+        const uint8_t* gp = bl + (int64_t)(y - kDescR) * p64 + xs + 16 * cc;
+        DwordQuad pv[8];
 #pragma unroll
-        for (int k = 0; k < 13; k++)                          // step 12: row 36 for every lane
-            pv[k] = *reinterpret_cast<const DwordPair*>((3 * k + 3 < kDescRows) ? gpl + 3 * k * p64 : gp + (kDescRows - 1) * p64);
+        for (int k = 0; k < 8; k++) {
+            const int row = (5 * k + 5 < kDescRows) ? 5 * k + rr : min(5 * k + rr, kDescRows - 1);
+            pv[k] = *reinterpret_cast<const DwordQuad*>(gp + row * p64);
+        }
 #pragma unroll
-        for (int k = 0; k < 13; k++) {
-            const int row = (3 * k + 3 < kDescRows) ? 3 * k + rr : kDescRows - 1;
-            *reinterpret_cast<uint2*>(sp + row * kDescPitch) = make_uint2(pv[k].lo, pv[k].hi);
+        for (int k = 0; k < 8; k++) {
+            const int row = (5 * k + 5 < kDescRows) ? 5 * k + rr : min(5 * k + rr, kDescRows - 1);
+            *reinterpret_cast<uint4*>(sp + row * kDescPitch) = make_uint4(pv[k].a, pv[k].b, pv[k].c, pv[k].d);
         }
     }
     int pitch;
@@ -828,29 +854,35 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     // a caller's level-0 image may be byte-aligned only (the level is the same for the wave's four keypoints)
     const bool raw_dword = __builtin_amdgcn_readfirstlane((l > 0) || S.aligned4) != 0;
     {
-        uint8_t* sr = s_raw[wv * 4 + grp] + 8 * cc;
-        const uint8_t* gp = img + (int64_t)(y - kHalfPatch) * pitch + xr + 8 * cc;
+        uint8_t* sr = s_raw[wv * 4 + grp] + 16 * cc;
         const int64_t p64 = pitch;
-        const uint8_t* gpl = gp + rr * p64;
-        DwordPair rv[11];
+        const uint8_t* gp = img + (int64_t)(y - kHalfPatch) * p64 + xr + 16 * cc;
+        DwordQuad rv[7];
         if (raw_dword) {
 #pragma unroll
-            for (int k = 0; k < 11; k++)                      // step 10: row 30 for every lane
-                rv[k] = *reinterpret_cast<const DwordPair*>((3 * k + 3 < 31) ? gpl + 3 * k * p64 : gp + 30 * p64);
+            for (int k = 0; k < 7; k++) {
+                const int row = (5 * k + 5 < 31) ? 5 * k + rr : min(5 * k + rr, 30);
+                rv[k] = *reinterpret_cast<const DwordQuad*>(gp + row * p64);
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const uint8_t* q = (3 * k + 3 < 31) ? gpl + 3 * k * p64 : gp + 30 * p64;
-                rv[k].lo = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-                rv[k].hi = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+            for (int k = 0; k < 7; k++) {
+                const int row = (5 * k + 5 < 31) ? 5 * k + rr : min(5 * k + rr, 30);
+                const uint8_t* q = gp + row * p64;
+                rv[k].a = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                rv[k].b = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+                rv[k].c = (uint32_t)q[8] | ((uint32_t)q[9] << 8) | ((uint32_t)q[10] << 16) | ((uint32_t)q[11] << 24);
+                rv[k].d = (uint32_t)q[12] | ((uint32_t)q[13] << 8) | ((uint32_t)q[14] << 16) | ((uint32_t)q[15] << 24);
             }
         }
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const int row = (3 * k + 3 < 31) ? 3 * k + rr : 30;
-            *reinterpret_cast<uint2*>(sr + row * kIcPitch) = make_uint2(rv[k].lo, rv[k].hi);
+        for (int k = 0; k < 7; k++) {
+            const int row = (5 * k + 5 < 31) ? 5 * k + rr : min(5 * k + rr, 30);
+            *reinterpret_cast<uint4*>(sr + row * kIcPitch) = make_uint4(rv[k].a, rv[k].b, rv[k].c, rv[k].d);
         }
     }
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+    DSTAMP(2);
     __builtin_amdgcn_wave_barrier();
 
     // ---- orb.cpp ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (integer, order-free) ----
@@ -877,6 +909,7 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     m10 = row16_sum(m10);
     m01 = row16_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+    DSTAMP(3);
 
     // ---- orb.cpp computeOrbDescriptors (WTA_K 2) on the blurred level, samples served from the LDS window ----
     float ang = angle;
@@ -897,6 +930,7 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     constexpr uint32_t kMagicBits = 0x4B400000u;          // bits of 1.5 * 2^23
     // mad_u24(by, pitch, bx) = ((by & 0xFFFFFF) * pitch) + bx = (0x400000 + iy) * pitch + kMagicBits + ix
     const uint8_t* bc0 = bc - (size_t)(0x400000u * (uint32_t)kDescPitch + kMagicBits);
+    DSTAMP(4);
     uint32_t mine = 0;
 #pragma unroll
     for (int it = 0; it < 16; it++) {
@@ -912,6 +946,7 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
         const unsigned long long m = __ballot(t0 < t1);
         if (l16 == it) mine = (uint32_t)(m >> (16 * grp)) & 0xFFFFu;
     }
+    DSTAMP(5);
     if (valid && fits) {
         const int64_t orow = (int64_t)frame * kp_cap + oidx;
         *reinterpret_cast<uint16_t*>(desc + orow * 32 + 2 * l16) = (uint16_t)mine;
@@ -926,6 +961,8 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
             kps[orow] = k;
         }
     }
+    DSTAMP(6);
+#undef DSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1042,8 +1079,28 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     {
         const int bpf = (P.sel_frame_entries + kDescKp - 1) / kDescKp;
         const int frames8 = (n_frames + 7) / 8 * 8;
+        static unsigned long long* d_stamps = nullptr;     // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
+        static int want_stamps = -1;
+        if (want_stamps < 0) { const char* e = getenv("ARIA_DESC_STAMPS"); want_stamps = (e && e[0] == '1') ? 1 : 0; }
+        const size_t nwaves = (size_t)bpf * frames8 * 2;
+        if (want_stamps && !d_stamps && nwaves <= (1u << 22)) hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * (1u << 22));
+        unsigned long long* stp = (want_stamps && nwaves <= (1u << 22)) ? d_stamps : nullptr;
+        if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
         ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(128), 0, st, P, S, D.raw, D.blur,
-                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf);
+                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp);
+        if (stp) {
+            hipStreamSynchronize(st);
+            std::vector<unsigned long long> hs(nwaves * 8);
+            hipMemcpy(hs.data(), stp, hs.size() * 8, hipMemcpyDeviceToHost);
+            double ph[6] = {0}; size_t n = 0;
+            for (size_t w = 0; w < nwaves; w++) {
+                if (!hs[w * 8 + 6]) continue;      // wave left early (empty slots)
+                for (int k = 0; k < 6; k++) ph[k] += (double)(hs[w * 8 + k + 1] - hs[w * 8 + k]);
+                n++;
+            }
+            if (n) fprintf(stderr, "[describe stamps] %zu waves, 100 MHz ticks: sel %.1f windows %.1f moments+atan %.1f sincos %.1f pattern %.1f store %.1f\n",
+                           n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n);
+        }
     }
     if (prof) prof->end(st);
 }
