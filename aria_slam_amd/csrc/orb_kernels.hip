@@ -48,6 +48,28 @@ __device__ __attribute__((aligned(16))) const PatternLaneMajor kPattern31 = make
 // computation in tests/test_host_logic.py)
 #define ARIA_UMAX_LIST {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3}
 
+// Byte masks of the radius-15 disc for k_describe's dword-wise IC moments, laid out like the pattern: lane
+// (hp = l16 >> 3, j = l16 & 7) owns patch columns u = 4j-15 .. 4j-12 of the rows v = 2k + hp - 15, k = 0..15, and
+// fetches its 16 masks [l16][k] with four 16-byte loads. 0xFF where |u| <= umax[|v|]; row 31 (k = 15, hp = 1) is zero.
+struct IcMaskLaneMajor { uint32_t m[16][16]; };
+constexpr IcMaskLaneMajor make_ic_mask() {
+    constexpr int umax[16] = ARIA_UMAX_LIST;
+    IcMaskLaneMajor t{};
+    for (int l = 0; l < 16; l++)
+        for (int k = 0; k < 16; k++) {
+            const int r = 2 * k + (l >> 3), j = l & 7;
+            uint32_t w = 0;
+            for (int b = 0; b < 4 && r < 31; b++) {
+                const int u = 4 * j + b - 15, v = r - 15;
+                const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+                if (au <= 15 && au <= umax[av]) w |= 0xFFu << (8 * b);
+            }
+            t.m[l][k] = w;
+        }
+    return t;
+}
+__device__ __attribute__((aligned(16))) const IcMaskLaneMajor kIcMask = make_ic_mask();
+
 // ------------------------------------------------------------------------------------------------------
 // a6.1  resize.cpp resize_bitExact<uchar, interpolationLinear>: H = c0*p[o] + c1*p[o+1] (exact, 8 frac bits),
 //       out = (cy0*H0 + cy1*H1 + 32768) >> 16. One thread = 4 adjacent output pixels = one dword store.
@@ -757,6 +779,14 @@ constexpr int kDescKp = 8;                  // keypoints per 128-thread workgrou
 constexpr int kIcPitch = 48;                // raw window: 31 rows x three 16-byte pieces (>= 31 + 3 bytes of alignment slack)
 struct __attribute__((packed, aligned(4))) DwordQuad { uint32_t a, b, c, d; };   // 16-byte load from a 4-byte-aligned address
 
+// sum over the aligned 8 lanes of a DPP half row
+__device__ __forceinline__ int row8_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    return v;
+}
+
 // sum over the 16 lanes of a DPP row (every lane of the row gets the total)
 __device__ __forceinline__ int row16_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
@@ -815,7 +845,13 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     DSTAMP(1);
 
-    // pattern rows of this lane (independent of the keypoint): issue early
+    // pattern rows and disc masks of this lane (independent of the keypoint): issue early
+    uint32_t icm[16];
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+        const uint4 m4 = *reinterpret_cast<const uint4*>(&kIcMask.m[l16][k]);
+        icm[k] = m4.x; icm[k + 1] = m4.y; icm[k + 2] = m4.z; icm[k + 3] = m4.w;
+    }
     int pat[16];
 #pragma unroll
     for (int it = 0; it < 16; it += 4) {
@@ -886,28 +922,32 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     __builtin_amdgcn_wave_barrier();
 
     // ---- orb.cpp ICAngles: m10 = sum u*I, m01 = sum v*I over the radius-15 disc (integer, order-free) ----
-    const uint8_t* ctr = s_raw[wv * 4 + grp] + kHalfPatch * kIcPitch + (x - xr);
-    constexpr int umax[16] = ARIA_UMAX_LIST;
-    const int ua = 2 * l16 - kHalfPatch, ub = ua + 1;      // ub == 16 for the last lane: outside every row
-    // Branch-free: a sample outside the disc is read (it is inside the staged window) and selected to 0. Column sums
-    // first -- m10 = ua * sum_v I(ua, v) + ub * sum_v I(ub, v) -- so a row costs two selects, three adds and one mad.
-    int sa = 0, sb = 0, m01 = 0;
+    // Dword-wise: lane (hp = l16 >> 3, j = l16 & 7) owns patch columns 4j-15 .. 4j-12 of the rows hp, hp+2, ...; a
+    // step realigns the window dword (64-bit shift by the keypoint's sub-dword offset), masks it to the disc and feeds
+    // three accumulators: sum (u+16) I and sum (v+16-hp) I by v_dot4_u32_u8 (unsigned weights), sum I by v_sad_u8.
+    const int sh = (x - xr) - kHalfPatch;                    // 0..3: window byte of patch column -15
+    const int hp = l16 >> 3, jj = l16 & 7;
+    const uint8_t* rbase = s_raw[wv * 4 + grp] + 4 * jj;
+    const uint32_t wu = 0x04030201u + 0x04040404u * (uint32_t)jj;      // (u + 16) for the lane's four columns
+    uint32_t acc_u = 0, acc_v = 0, acc_s = 0;
 #pragma unroll
-    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
-        const int d = umax[v < 0 ? -v : v];
-        const uint8_t* rowp = ctr + v * kIcPitch;
-        // volatile: keep the two LDS reads unconditional (otherwise each one is wrapped in an exec-mask branch)
-        typedef const volatile __attribute__((address_space(3))) uint8_t* lds_vptr;
-        const int ra = *(lds_vptr)(rowp + ua), rb = *(lds_vptr)(rowp + ub);
-        const int va = (abs(ua) <= d) ? ra : 0;
-        const int vb = (abs(ub) <= d) ? rb : 0;
-        sa += va;
-        sb += vb;
-        m01 += v * (va + vb);
+    for (int k = 0; k < 16; k++) {
+        const int r = min(2 * k + hp, 30);                   // k == 15, hp == 1: padding step, its mask is 0
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(rbase + r * kIcPitch);
+        const uint32_t hi = *reinterpret_cast<const uint32_t*>(rbase + r * kIcPitch + 4);
+        const uint32_t pix = __builtin_amdgcn_alignbyte(hi, lo, sh) & icm[k];
+        acc_u = __builtin_amdgcn_udot4(pix, wu, acc_u, false);
+        acc_v = __builtin_amdgcn_udot4(pix, 0x01010101u * (uint32_t)(2 * k + 1), acc_v, false);   // v + 16 - hp = 2k + 1
+        acc_s = __builtin_amdgcn_sad_u8(pix, 0u, acc_s);
     }
-    int m10 = ua * sa + ub * sb;
-    m10 = row16_sum(m10);
-    m01 = row16_sum(m01);
+    const int sum_u = row16_sum((int)acc_u), sum_v = row16_sum((int)acc_v);
+    // rows of one parity live in one half of the DPP row: sum I per half for the hp term, total for the -16 terms
+    const int s_half = row8_sum((int)acc_s);                  // sum I over this lane's 8-lane half (one row parity)
+    const int s_othr = __builtin_amdgcn_update_dpp(0, s_half, 0x140, 0xF, 0xF, true);   // row_mirror: the other half's sum
+    const int s_all = s_half + s_othr;
+    const int s_hp1 = hp ? s_half : s_othr;                   // sum I over the odd rows (hp == 1)
+    const int m10 = sum_u - 16 * s_all;
+    const int m01 = sum_v + s_hp1 - 16 * s_all;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     DSTAMP(3);
 
