@@ -181,8 +181,19 @@ __global__ __launch_bounds__(256) void k_resize(Plan P, FrameSrc S, uint8_t* __r
 // (~1.2 * band + 2) are staged with coalesced 16-byte loads, 4 in flight per lane, so the texture path sees wide
 // contiguous requests instead of three overlapping dword gathers per lane; the x table and the band's y slice ride
 // along in LDS; the bilinear taps are then dword windows read from LDS.
+//
+// DOT2 (default): the per-pixel arithmetic runs on v_perm_b32 + v_dot2_u32_u16. The x table is widened at staging
+// time to three words per output column -- (256-cx1) | cx1 << 16, the dword-aligned source offset, and the v_perm
+// selector that lifts the two source bytes into two u16 lanes -- kept as three arrays so that a lane fetches the four
+// columns of its output dword with three conflict-free ds_read_b128. A pixel is then: two ds_read2_b32 (source
+// dword pair in both rows), 2 v_perm + 2 v_dot2 (horizontal pass, both rows), 1 v_lshl_or + 1 v_dot2 with
+// the rounding constant as accumulator (vertical pass), 1 v_perm that drops the result byte into the output dword:
+// 9 vector-ALU instructions per pixel where the shift/extract/mad form needed ~30 (this kernel is VALU-issue bound).
+// Same integers as the reference's ufixedpoint16 arithmetic: (256-c)*p0 + c*p1 is what it evaluates.
 constexpr int kResizeBand = 16;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
+template <bool DOT2>
 __global__ __launch_bounds__(256) void k_resize_lds(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
                                                     const uint32_t* __restrict__ tab, int l) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_rs[];
@@ -195,13 +206,24 @@ __global__ __launch_bounds__(256) void k_resize_lds(Plan P, FrameSrc S, uint8_t*
     const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
     const int lp = (sw + 15) / 16 * 16 + 16;                     // LDS pitch of a staged source row (+16: window slack)
     const int max_rows = (kResizeBand * 13) / 10 + 4;            // rows a band can need at scale ~1.2
-    uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_rs + max_rows * lp);
-    uint32_t* s_yt = s_xt + g.w;
+    uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_rs + max_rows * lp);      // 16-byte aligned: lp is a multiple of 16
+    const int w4 = (g.w + 3) & ~3;
+    uint32_t* s_yt = s_xt + (DOT2 ? 3 * w4 : g.w);
     const uint32_t* ytg = tab + g.ytab + dy0;
     const int oy_lo = (int)(ytg[0] & 0xFFFF);
     const int oy_hi = min((int)(ytg[ndy - 1] & 0xFFFF) + 1, sh - 1);
     const int nrows = min(oy_hi - oy_lo + 1, max_rows);
-    for (int i = tid; i < g.w; i += 256) s_xt[i] = tab[g.xtab + i];
+    if (DOT2) {
+        for (int i = tid; i < w4; i += 256) {                 // columns past the level repeat the last one
+            const uint32_t t = tab[g.xtab + min(i, g.w - 1)];
+            const uint32_t ox = t & 0xFFFFu, cx1 = t >> 16;
+            s_xt[i] = (256u - cx1) | (cx1 << 16);
+            s_xt[w4 + i] = ox & ~3u;
+            s_xt[2 * w4 + i] = 0x0C010C00u + (ox & 3u) * 0x00010001u;
+        }
+    } else {
+        for (int i = tid; i < g.w; i += 256) s_xt[i] = tab[g.xtab + i];
+    }
     if (tid < ndy) s_yt[tid] = ytg[tid];
     const bool a16 = (l > 1) || S.aligned16;
     const int nch = a16 ? (sw >> 4) : 0;
@@ -245,7 +267,35 @@ __global__ __launch_bounds__(256) void k_resize_lds(Plan P, FrameSrc S, uint8_t*
         const int gx = it - r * groups;
         const int dx0 = gx * 4;
         uint32_t outw = 0;
-        if (dx0 < g.w) {
+        if (DOT2) {
+            if (dx0 < g.w) {
+                const uint32_t ty = s_yt[r];
+                const int oy = ty & 0xFFFF;
+                const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
+                const int ra = min(oy - oy_lo, nrows - 1), rb = min(min(oy + 1, sh - 1) - oy_lo, nrows - 1);
+                const uint8_t* rowa = smem_rs + ra * lp;
+                const uint8_t* rowb = smem_rs + rb * lp;
+                const uint4 xw = *reinterpret_cast<const uint4*>(s_xt + dx0);
+                const uint4 xo = *reinterpret_cast<const uint4*>(s_xt + w4 + dx0);
+                const uint4 xs = *reinterpret_cast<const uint4*>(s_xt + 2 * w4 + dx0);
+                const uint32_t xwv[4] = {xw.x, xw.y, xw.z, xw.w}, xov[4] = {xo.x, xo.y, xo.z, xo.w},
+                               xsv[4] = {xs.x, xs.y, xs.z, xs.w};
+                constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xov[i]);
+                    const uint32_t* qb = reinterpret_cast<const uint32_t*>(rowb + xov[i]);
+                    const uint32_t top = __builtin_amdgcn_perm(qa[1], qa[0], xsv[i]);     // p00 | p01 << 16
+                    const uint32_t bot = __builtin_amdgcn_perm(qb[1], qb[0], xsv[i]);
+                    const us2 wx = __builtin_bit_cast(us2, xwv[i]);
+                    const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, top), wx, 0u, false);
+                    const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bot), wx, 0u, false);
+                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, h0 | (h1 << 16)),
+                                                              __builtin_bit_cast(us2, cyp), 32768u, false);   // < 2^24
+                    outw = __builtin_amdgcn_perm(v, outw, put[i]);
+                }
+            }
+        } else if (dx0 < g.w) {
             const uint32_t ty = s_yt[r];
             const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
             uint32_t tx[4];
@@ -1073,15 +1123,19 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S,
                     D.raw, D.tab, D.pyr_bands);
     } else {
-        static int rs_impl = -1;    // 1 = LDS-staged bands (default), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)
-        if (rs_impl < 0) { const char* e = getenv("ARIA_RESIZE_IMPL"); rs_impl = (e && e[0] == 'd') ? 0 : 1; }
+        // 2 = LDS-staged bands with dot2 arithmetic (default), 1 = LDS-staged bands with shift/mad arithmetic
+        // (ARIA_RESIZE_IMPL=lds), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)
+        static int rs_impl = -1;
+        if (rs_impl < 0) { const char* e = getenv("ARIA_RESIZE_IMPL"); rs_impl = (e && e[0] == 'd') ? 0 : (e && e[0] == 'l') ? 1 : 2; }
         for (int l = 1; l < kLevels; l++) {
-            if (rs_impl == 1) {
+            if (rs_impl >= 1) {
                 const int lp = (P.lv[l - 1].w + 15) / 16 * 16 + 16;
-                const size_t lds = (size_t)((kResizeBand * 13) / 10 + 4) * lp + sizeof(uint32_t) * ((size_t)P.lv[l].w + kResizeBand) + 16;
+                const size_t xt_words = rs_impl == 2 ? 3 * (size_t)((P.lv[l].w + 3) & ~3) : (size_t)P.lv[l].w;
+                const size_t lds = (size_t)((kResizeBand * 13) / 10 + 4) * lp + sizeof(uint32_t) * (xt_words + kResizeBand) + 16;
                 if (lds <= 64 * 1024) {
-                    ARIA_LAUNCH(prof, k_resize_lds, dim3((P.lv[l].h + kResizeBand - 1) / kResizeBand, n_frames),
-                                dim3(256), lds, st, P, S, D.raw, D.tab, l);
+                    const dim3 grid((P.lv[l].h + kResizeBand - 1) / kResizeBand, n_frames);
+                    if (rs_impl == 2) ARIA_LAUNCH(prof, k_resize_lds<true>, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
+                    else ARIA_LAUNCH(prof, k_resize_lds<false>, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
                     continue;
                 }
             }

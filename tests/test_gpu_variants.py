@@ -14,6 +14,7 @@ VARIANTS = [
     {},
     {"ARIA_FAST_BLUR_IMPL": "tile"},
     {"ARIA_RESIZE_IMPL": "direct"},
+    {"ARIA_RESIZE_IMPL": "lds"},                                   # LDS-staged resize with shift/mad arithmetic
     {"ARIA_PYRAMID_IMPL": "fused"},
     {"ARIA_LEVEL_STREAMS": "1"},
     {"ARIA_BAND_QPCT0": "1", "ARIA_BAND_QPCT_STEP": "0"},          # survivor queue overflows -> slow path
