@@ -824,7 +824,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 // level (dword-aligned start) holds every sample of a keypoint.
 constexpr int kDescR = 18;
 constexpr int kDescRows = 2 * kDescR + 1;   // 37
-constexpr int kDescPitch = 48;              // three 16-byte pieces per row (>= 37 + 3 bytes of alignment slack)
+constexpr int kDescPitch = 64;              // four 16-byte-ALIGNED pieces per row (>= 37 + 15 bytes of alignment slack)
 constexpr int kDescKp = 8;                  // keypoints per 128-thread workgroup: 2 waves x 4 DPP rows
 constexpr int kIcPitch = 48;                // raw window: 31 rows x three 16-byte pieces (>= 31 + 3 bytes of alignment slack)
 struct __attribute__((packed, aligned(4))) DwordQuad { uint32_t a, b, c, d; };   // 16-byte load from a 4-byte-aligned address
@@ -861,8 +861,10 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     // diagnostic only (ARIA_DESC_STAMPS=1): s_memtime at the phase boundaries of every wave
 #define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     DSTAMP(0);
+    // One LDS window per keypoint, used twice: first the raw 31 x 48 window (IC moments), then -- once the moments are
+    // reduced -- the blurred 37 x 64 window, which has been waiting in registers since both were requested together.
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[kDescKp][kDescRows * kDescPitch];
-    __shared__ __attribute__((aligned(16))) uint8_t s_raw[kDescKp][31 * kIcPitch];
+    uint8_t (*s_raw)[kDescRows * kDescPitch] = s_patch;
     // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
     // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -909,36 +911,34 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
         pat[it] = (int)p4.x; pat[it + 1] = (int)p4.y; pat[it + 2] = (int)p4.z; pat[it + 3] = (int)p4.w;
     }
 
-    // ---- stage the blurred 37 x 48 and the raw 31 x 48 window of each keypoint in LDS. The texture-address path, not
-    //      bandwidth, bounds this kernel (TA busy 75-80 % with 8-byte loads), and it charges per instruction: so 16-byte
-    //      loads, lane -> (row mod 5, 16-byte piece): 15 lanes fetch five whole rows per instruction, the next address
-    //      is one add, and no lane is ever masked -- lane 15 (rr == 5) and the lanes past the last row repeat a
-    //      (row, piece) that another lane or step also writes: same address, same data. The 48 bytes end <= 33 px
-    //      right of a keypoint that is >= 31 px inside the level, on rows >= 16 above the last: never past the image. ----
+    // ---- request the blurred 37 x 64 and the raw 31 x 48 window of each keypoint with 16-byte loads. What bounds this
+    //      kernel is the L1 (TCP) access rate: one 64-byte access per clock per CU, and a 16-byte lane load that is not
+    //      16-byte aligned, or whose neighbours in the same 64-byte chunk sit in other instructions, costs an access of
+    //      its own (245 accesses per keypoint = one per lane load, measured). So: pieces are 16-byte ALIGNED (window
+    //      origin rounded down to 16), and the lanes of an instruction cover whole rows, piece by piece, so that the
+    //      pieces of one 64-byte chunk are adjacent lanes and coalesce. No lane is ever masked: lanes past the last
+    //      row repeat a (row, piece) that another lane or step also holds. The windows end <= 45 px right of a
+    //      keypoint that is >= 31 px inside the level, on rows >= 16 above the last: never past the image. ----
     const uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
-    const int xs = (x - kDescR) & ~3;                      // dword-aligned first column
-    const int rr = l16 / 3, cc = l16 - 3 * rr;
+    const int xs = (x - kDescR) & ~15;                     // 16-byte aligned first column (pitch and bases are too)
+    DwordQuad pv[10];                                      // blurred window, parked in registers until the moments are done
     {
-        uint8_t* sp = s_patch[wv * 4 + grp] + 16 * cc;
+        const int r4 = l16 >> 2, c4 = l16 & 3;             // lane -> (row mod 4, piece): four whole rows per instruction
         const int64_t p64 = g.pitch;
-        const uint8_t* gp = bl + (int64_t)(y - kDescR) * p64 + xs + 16 * cc;
-        DwordQuad pv[8];
+        const uint8_t* gp = bl + (int64_t)(y - kDescR) * p64 + xs + 16 * c4;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int row = (5 * k + 5 < kDescRows) ? 5 * k + rr : min(5 * k + rr, kDescRows - 1);
+        for (int k = 0; k < 10; k++) {
+            const int row = (4 * k + 4 <= kDescRows) ? 4 * k + r4 : min(4 * k + r4, kDescRows - 1);
             pv[k] = *reinterpret_cast<const DwordQuad*>(gp + row * p64);
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int row = (5 * k + 5 < kDescRows) ? 5 * k + rr : min(5 * k + rr, kDescRows - 1);
-            *reinterpret_cast<uint4*>(sp + row * kDescPitch) = make_uint4(pv[k].a, pv[k].b, pv[k].c, pv[k].d);
-        }
     }
+    const int rr = l16 / 3, cc = l16 - 3 * rr;             // raw window: lane -> (row mod 5, piece), five rows per instruction
     int pitch;
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
-    const int xr = (x - kHalfPatch) & ~3;
-    // a caller's level-0 image may be byte-aligned only (the level is the same for the wave's four keypoints)
+    // a caller's level-0 image may be only 4- or 1-byte aligned (the level is the same for the wave's four keypoints)
     const bool raw_dword = __builtin_amdgcn_readfirstlane((l > 0) || S.aligned4) != 0;
+    const bool raw_a16 = __builtin_amdgcn_readfirstlane((l > 0) || S.aligned16) != 0;
+    const int xr = raw_a16 ? ((x - kHalfPatch) & ~15) : ((x - kHalfPatch) & ~3);   // x - 15 - xr in 0..15: 31 + 15 < 48
     {
         uint8_t* sr = s_raw[wv * 4 + grp] + 16 * cc;
         const int64_t p64 = pitch;
@@ -975,9 +975,9 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     // Dword-wise: lane (hp = l16 >> 3, j = l16 & 7) owns patch columns 4j-15 .. 4j-12 of the rows hp, hp+2, ...; a
     // step realigns the window dword (64-bit shift by the keypoint's sub-dword offset), masks it to the disc and feeds
     // three accumulators: sum (u+16) I and sum (v+16-hp) I by v_dot4_u32_u8 (unsigned weights), sum I by v_sad_u8.
-    const int sh = (x - xr) - kHalfPatch;                    // 0..3: window byte of patch column -15
+    const int sh = (x - xr) - kHalfPatch;                    // 0..15: window byte of patch column -15
     const int hp = l16 >> 3, jj = l16 & 7;
-    const uint8_t* rbase = s_raw[wv * 4 + grp] + 4 * jj;
+    const uint8_t* rbase = s_raw[wv * 4 + grp] + 4 * jj + (sh & ~3);
     const uint32_t wu = 0x04030201u + 0x04040404u * (uint32_t)jj;      // (u + 16) for the lane's four columns
     uint32_t acc_u = 0, acc_v = 0, acc_s = 0;
 #pragma unroll
@@ -1007,6 +1007,16 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     double sd, cd;
     det_sincos((double)ang, sd, cd);
     const float a = (float)cd, b = (float)sd;
+    __builtin_amdgcn_wave_barrier();                       // every lane of the wave is done reading the raw window
+    {
+        const int r4 = l16 >> 2, c4 = l16 & 3;
+        uint8_t* sp = s_patch[wv * 4 + grp] + 16 * c4;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int row = (4 * k + 4 <= kDescRows) ? 4 * k + r4 : min(4 * k + r4, kDescRows - 1);
+            *reinterpret_cast<uint4*>(sp + row * kDescPitch) = make_uint4(pv[k].a, pv[k].b, pv[k].c, pv[k].d);
+        }
+    }
     const uint8_t* bc = s_patch[wv * 4 + grp] + kDescR * kDescPitch + (x - xs);     // window address of the keypoint centre
     __builtin_amdgcn_wave_barrier();
     // Both samples of a test ride in one register pair: (fx0, fx1) = (px0, px1) * a + (py0, py1) * (-b) and
