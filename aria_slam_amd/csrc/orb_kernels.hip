@@ -661,10 +661,13 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
 __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint2* __restrict__ sel, int* __restrict__ sel_cnt,
-                                                int* __restrict__ err) {
+                                                int* __restrict__ err, unsigned long long* __restrict__ stamps) {
+#define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    SSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
     __shared__ int s_hist[256];
     __shared__ int s_misc[4];   // [0] threshold score, [1] n1, [2] n2
+    __shared__ int s_wsum[4];
 
     const int tid = threadIdx.x;
     const int l = blockIdx.x, frame = blockIdx.y;
@@ -681,38 +684,89 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     s_hist[tid] = 0;
     if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[clist[i] >> 22], 1);
-    __syncthreads();
-    // keypoint.cpp retainBest(2*quota) on the FAST score: keep every score >= the (2q)-th largest
-    if (tid == 0) {
-        int thr = 0;
-        if (n > 2 * q) {
-            int cum = 0;
-            for (int s = 255; s >= 0; s--) {
-                cum += s_hist[s];
-                if (cum >= 2 * q) { thr = s; break; }
-            }
+    // The candidate list is walked twice. Eight independent loads per lane and trip: a load-then-use loop pays one
+    // global round trip per 256 candidates, which is what this kernel used to spend most of its time on.
+    constexpr int kUnroll = 8;
+    for (int i0 = 0; i0 < n; i0 += 256 * kUnroll) {
+        uint32_t v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const int i = i0 + u * 256 + tid;
+            v[u] = i < n ? clist[i] : 0u;
         }
-        s_misc[0] = thr;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++)
+            if (i0 + u * 256 + tid < n) atomicAdd(&s_hist[v[u] >> 22], 1);
     }
     __syncthreads();
+    SSTAMP(1);
+    // keypoint.cpp retainBest(2*quota) on the FAST score: keep every score >= the (2q)-th largest
+    // = the largest score s whose suffix count sum_{s' >= s} hist[s'] reaches 2q (0 if there are at most 2q). Thread
+    // t owns bin 255 - t, so the suffix count is an inclusive prefix sum over threads: wave scan (DPP-free shuffles)
+    // + three wave totals through LDS. (A single lane walking the 256 bins cost every workgroup ~20k cycles.)
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        int c = s_hist[255 - tid];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(c, d);
+            if (lane >= d) c += o;
+        }
+        if (lane == 63) s_wsum[wv] = c;
+        if (tid == 0) s_misc[0] = 0;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+            if (w < wv) before += s_wsum[w];
+        const int cum = c + before;                                     // sum of hist[255 - tid ..255]
+        const int own = s_hist[255 - tid];
+        // exactly one thread sees the count cross 2q (if it crosses at all)
+        if (n > 2 * q && cum >= 2 * q && cum - own < 2 * q) s_misc[0] = 255 - tid;
+        __syncthreads();
+    }
     const int thr = s_misc[0];
+    // survivors of the cut are first compacted into the key array (record in the low word) ...
+    for (int i0 = 0; i0 < n; i0 += 256 * kUnroll) {
+        uint32_t v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const int i = i0 + u * 256 + tid;
+            v[u] = i < n ? clist[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const bool keep = i0 + u * 256 + tid < n && (int)(v[u] >> 22) >= thr;
+            const unsigned long long m = __ballot(keep);                // one LDS atomic per wave, not per survivor
+            if (m) {
+                const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(m));
+                base = __shfl(base, leader);
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && slot < kSortCap) s_keys[slot] = (unsigned long long)v[u];
+            }
+        }
+    }
+    __syncthreads();
+    SSTAMP(2);
+    // ... then every lane scores its share of them: balanced, and the 27 window loads of a Harris response are the
+    // only latency left in the loop
     int pitch;
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
-    for (int i = tid; i < n; i += 256) {
-        const uint32_t cd = clist[i];
-        if ((int)(cd >> 22) >= thr) {
+    {
+        const int ns = min(s_misc[1], kSortCap);
+        for (int i = tid; i < ns; i += 256) {
+            const uint32_t cd = (uint32_t)s_keys[i];
             const int x = cd & 0x7FF, y = (cd >> 11) & 0x7FF;
-            const int slot = atomicAdd(&s_misc[1], 1);
-            if (slot < kSortCap) {
-                const float r = harris_response(img, pitch, x, y, (l > 0) || S.aligned4);
-                uint32_t u = __float_as_uint(r);
-                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order integer image of the float
-                s_keys[slot] = ((unsigned long long)(~u) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
-            }
+            const float r = harris_response(img, pitch, x, y, (l > 0) || S.aligned4);
+            uint32_t u = __float_as_uint(r);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order integer image of the float
+            s_keys[i] = ((unsigned long long)(~u) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
         }
     }
     __syncthreads();
+    SSTAMP(3);
     int n1 = s_misc[1];
     if (n1 > kSortCap) {
         if (tid == 0) atomicOr(err, ERRBIT_SORT_OVERFLOW);
@@ -723,18 +777,30 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     for (int i = n1 + tid; i < np; i += 256) s_keys[i] = ~0ull;
     __syncthreads();
     // bitonic sort, ascending on (~harris_order, y, x) == Harris descending, then y, then x
+    // Thread t of a step owns the pair (i0, i0 | j); for j <= 64 the 64 threads of a wave own one aligned block of 128
+    // keys and every partner stays inside it, so those steps need no workgroup barrier -- the wave's LDS accesses are
+    // served in order. Of the 55 steps of a 1024-key sort only the 6 with j >= 128 (and the steps next to them)
+    // synchronise the workgroup.
     for (int k = 2; k <= np; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (np >> 1); t += 256) {
-                const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int i1 = i0 | j;
-                const unsigned long long a = s_keys[i0], b = s_keys[i1];
-                const bool up = (i0 & k) == 0;
-                if ((a > b) == up) { s_keys[i0] = b; s_keys[i1] = a; }
+            // two pairs per thread and trip, all four keys requested before the first compare: one LDS round trip
+            // per step instead of one per pair
+            for (int t0 = tid; t0 < (np >> 1); t0 += 512) {
+                const int ta = t0, tb = t0 + 256;
+                const bool hb = tb < (np >> 1);
+                const int a0 = ((ta & ~(j - 1)) << 1) | (ta & (j - 1)), a1 = a0 | j;
+                const int b0 = hb ? (((tb & ~(j - 1)) << 1) | (tb & (j - 1))) : a0, b1 = hb ? (b0 | j) : a1;
+                const unsigned long long xa = s_keys[a0], ya = s_keys[a1], xb = s_keys[b0], yb = s_keys[b1];
+                if ((xa > ya) == ((a0 & k) == 0)) { s_keys[a0] = ya; s_keys[a1] = xa; }
+                if (hb && (xb > yb) == ((b0 & k) == 0)) { s_keys[b0] = yb; s_keys[b1] = xb; }
             }
-            __syncthreads();
+            const int next_j = j > 1 ? (j >> 1) : k;     // first step of the next k is j = k
+            if (j >= 128 || next_j >= 128) __syncthreads();
+            else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
         }
     }
+    __syncthreads();
+    SSTAMP(4);
     // retainBest(quota) on Harris: first q plus everything tying with the q-th
     int n2 = n1;
     if (n1 > q) {
@@ -756,6 +822,8 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         out[i] = make_uint2((uint32_t)kk, u);   // (x | y << 16, harris bits)
     }
     if (tid == 0) sel_cnt[frame * kLevels + l] = n2;
+    SSTAMP(5);
+#undef SSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1173,8 +1241,29 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
 
     // ---- a6.3-a6.5 selection ----
     if (prof) prof->begin(STAGE_SELECT, st);
+    static unsigned long long* d_sstamps = nullptr;     // diagnostic: ARIA_SEL_STAMPS=1 prints mean phase lengths per level
+    static const int want_sstamps = [] { const char* e = getenv("ARIA_SEL_STAMPS"); return (e && e[0] == '1') ? 1 : 0; }();
+    if (want_sstamps && !d_sstamps) hipMalloc(&d_sstamps, sizeof(unsigned long long) * 8 * kLevels * 4096);
+    unsigned long long* sstp = (want_sstamps && n_frames <= 4096) ? d_sstamps : nullptr;
+    if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
     ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
-                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err);
+                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp);
+    if (sstp) {
+        hipStreamSynchronize(st);
+        std::vector<unsigned long long> hs((size_t)n_frames * kLevels * 8);
+        hipMemcpy(hs.data(), sstp, hs.size() * 8, hipMemcpyDeviceToHost);
+        for (int l = 0; l < kLevels; l += 7) {
+            double ph[5] = {0}; int n = 0;
+            for (int f = 0; f < n_frames; f++) {
+                const unsigned long long* q = &hs[((size_t)f * kLevels + l) * 8];
+                if (!q[5]) continue;
+                for (int k = 0; k < 5; k++) ph[k] += (double)(q[k + 1] - q[k]);
+                n++;
+            }
+            if (n) fprintf(stderr, "[select stamps L%d] %d blocks, cycles: hist %.0f cut+compact %.0f harris %.0f sort %.0f emit %.0f\n",
+                           l, n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n);
+        }
+    }
 
     if (prof) prof->end(st);
 
