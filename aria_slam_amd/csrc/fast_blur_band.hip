@@ -221,9 +221,9 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
         const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
 
         // 7-row register window; slot = step % 7 (static after unrolling by 7)
-        uint32_t RS[7][4], RC[7], RE[7], RW[7];
+        uint32_t RS[7][4], RC2[7][2], RE[7], RW[7];
 #pragma unroll
-        for (int u = 0; u < 7; u++) { RC[u] = RE[u] = RW[u] = 0; RS[u][0] = RS[u][1] = RS[u][2] = RS[u][3] = 0; }
+        for (int u = 0; u < 7; u++) { RC2[u][0] = RC2[u][1] = RE[u] = RW[u] = 0; RS[u][0] = RS[u][1] = RS[u][2] = RS[u][3] = 0; }
 
         const uint32_t* lrow = reinterpret_cast<const uint32_t*>(s_pix) + (sb * kBandR) * dpr + li;
         for (int tb = 0; tb < kStripRows; tb += 7) {
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                 if (t < kStripRows) {
                     const uint32_t* rp = lrow + t * dpr;
                     const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
-                    RC[u] = w1;
+                    RC2[u][0] = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);   // px 0, 1 as int16 pair
+                    RC2[u][1] = __builtin_amdgcn_perm(0u, w1, 0x0c030c02u);   // px 2, 3
                     RW[u] = __builtin_amdgcn_alignbyte(w1, w0, 1);     // x-3 .. x
                     RE[u] = __builtin_amdgcn_alignbyte(w2, w1, 3);     // x+3 .. x+6
                     RS[u][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), KHI,
@@ -270,19 +271,20 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                     if (o >= o_min && o <= o_max && Y >= fy0 && Y <= fy1) {
                         // compass reject, two pixels per packed-int16 op: survive iff (N|S)&(E|W) are all darker than
                         // c - t or all brighter than c + t (every 9-arc holds one pixel of each antipodal compass pair)
+                        // darker: both compass pairs have a member below c - t  <=>  max(min(n, s), min(e, w)) < c - t;
+                        // brighter: min(max(n, s), max(e, w)) > c + t. The centre row's bytes were widened to int16
+                        // pairs when the row entered the window (it serves as n, c and s of three output rows).
                         uint32_t pass[2];
 #pragma unroll
                         for (int pr = 0; pr < 2; pr++) {
                             const uint32_t sel = pr ? 0x0c030c02u : 0x0c010c00u;
-                            const uint32_t c2 = __builtin_amdgcn_perm(0u, RC[sC], sel);
-                            const uint32_t n2 = __builtin_amdgcn_perm(0u, RC[sM3], sel);
-                            const uint32_t s2 = __builtin_amdgcn_perm(0u, RC[sP3], sel);
+                            const uint32_t c2 = RC2[sC][pr], n2 = RC2[sM3][pr], s2 = RC2[sP3][pr];
                             const uint32_t e2 = __builtin_amdgcn_perm(0u, RE[sC], sel);
                             const uint32_t w2p = __builtin_amdgcn_perm(0u, RW[sC], sel);
                             const uint32_t lo = pk_sub_i16(c2, T2), hi = pk_add_i16(c2, T2);
                             // sign bit set <=> darker than c - t / brighter than c + t
-                            const uint32_t dk = (pk_sub_i16(n2, lo) | pk_sub_i16(s2, lo)) & (pk_sub_i16(e2, lo) | pk_sub_i16(w2p, lo));
-                            const uint32_t br = (pk_sub_i16(hi, n2) | pk_sub_i16(hi, s2)) & (pk_sub_i16(hi, e2) | pk_sub_i16(hi, w2p));
+                            const uint32_t dk = pk_sub_i16(pk_max_i16(pk_min_i16(n2, s2), pk_min_i16(e2, w2p)), lo);
+                            const uint32_t br = pk_sub_i16(hi, pk_min_i16(pk_max_i16(n2, s2), pk_max_i16(e2, w2p)));
                             pass[pr] = (dk | br) & (pr ? xm1 : xm0);
                         }
                         accw |= (pass[0] | (pass[1] >> 1)) >> (2 * u);
