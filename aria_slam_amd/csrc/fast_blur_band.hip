@@ -216,6 +216,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
         uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off + x;
         const int body = w & ~3;   // SymmColumnVec_32s8u (ties to even) covers x < (w & ~3); the scalar tail rounds ties up
         const bool tie_even_lane = TIE_EVEN && (x < body);
+        const uint32_t rnd_bias = tie_even_lane ? 0x7FFFu : 0x8000u, rnd_odd = tie_even_lane ? 1u : 0u;
 
         const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
         const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
@@ -254,15 +255,17 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                     if (o >= 0 && o < kBandR && Y < h) {
                         // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u)
                         uint32_t outw = 0;
+                        constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of r -> byte j
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             // operands < 2^24: 24-bit multiplies (v_mad_u32_u24) are full rate, v_mul_lo_u32 is not
-                            uint32_t acc = umad24(55u, RS[sC][j], 32768u);
+                            uint32_t acc = __umul24(55u, RS[sC][j]);
                             acc = umad24(49u, RS[sM1][j] + RS[sP1][j], acc);
                             acc = umad24(34u, RS[sM2][j] + RS[sP2][j], acc);
                             acc = umad24(18u, RS[sM3][j] + RS[sP3][j], acc);
-                            if (tie_even_lane && (acc & 0x1FFFFu) == 0x10000u) acc -= 0x10000u;   // exact tie, odd quotient -> even
-                            outw |= min(acc >> 16, 255u) << (8 * j);
+                            // round by 2^16: ties to even = + 0x7FFF + (quotient odd), ties up = + 0x8000; saturate to 255
+                            const uint32_t r = acc + rnd_bias + ((acc >> 16) & rnd_odd);
+                            outw = __builtin_amdgcn_perm(min(r, 0x00FFFFFFu), outw, put[j]);
                         }
                         *reinterpret_cast<uint32_t*>(bl + (int64_t)Y * g.pitch) = outw;
                     }
