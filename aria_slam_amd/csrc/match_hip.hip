@@ -210,6 +210,7 @@ struct aria_matcher_s {
     int* h_idx = nullptr;           // pinned
     // optional stage timing (HIP events on the launch stream)
     bool prof_enabled = false;
+    unsigned prof_mask = ~0u;       // bit s: bracket stage s (0 knn2, 1 ratio_compact)
     struct Ev { hipEvent_t e[4]; int pairs; };
     std::vector<Ev> prof_pending;
     std::vector<hipEvent_t> prof_pool;
@@ -225,12 +226,13 @@ struct aria_matcher_s {
     void prof_collect() {
         for (Ev& v : prof_pending) {
             for (int s = 0; s < 2; s++) {
+                if (!v.e[2 * s]) continue;          // stage not bracketed
                 float t = 0.f;
                 if (hipEventElapsedTime(&t, v.e[2 * s], v.e[2 * s + 1]) == hipSuccess) prof_ms[s] += t;
                 prof_launches[s] += 1;
             }
             prof_pairs += v.pairs;
-            for (int s = 0; s < 4; s++) prof_pool.push_back(v.e[s]);
+            for (int s = 0; s < 4; s++) if (v.e[s]) prof_pool.push_back(v.e[s]);
         }
         prof_pending.clear();
     }
@@ -359,6 +361,7 @@ void* aria_matcher_stream(aria_matcher_t m) { return m ? (void*)m->stream : null
 int aria_matcher_set_profiling(aria_matcher_t m, int enable) {
     if (!m) return ARIA_E_INVALID;
     m->prof_enabled = enable != 0;
+    m->prof_mask = (enable & 1) ? ~0u : ((unsigned)enable >> 1);
     return ARIA_OK;
 }
 
@@ -446,24 +449,28 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
     ARIA_HIP(hipSetDevice(m->device));
     int rc = ensure_keys(m, (size_t)n_pairs * (size_t)maxq);
     if (rc != ARIA_OK) return rc;
-    // profiling: drain the stream, then bracket each kernel with an event pair (see orb_kernels.h Profiler)
+    // profiling: drain the stream, then bracket the selected kernels with an event pair (see orb_kernels.h Profiler)
     aria_matcher_s::Ev ev;
     ev.pairs = n_pairs;
-    if (m->prof_enabled) {
-        for (int s = 0; s < 4; s++) ev.e[s] = m->prof_get();
+    const bool p0 = m->prof_enabled && (m->prof_mask & 1u), p1 = m->prof_enabled && (m->prof_mask & 2u);
+    for (int s = 0; s < 4; s++) ev.e[s] = nullptr;
+    if (p0) {
+        ev.e[0] = m->prof_get(); ev.e[1] = m->prof_get();
         hipStreamSynchronize(m->stream);
         hipEventRecord(ev.e[0], m->stream);
     }
     launch_knn2(m, 0, (int)maxq, n_pairs, d_query, d_nq, 0, d_train, d_nt, 0, desc_stride,
                 desc_stride, m->d_keys, (int)maxq, 0.0, nullptr, (int)maxq);
-    if (m->prof_enabled) {
-        hipEventRecord(ev.e[1], m->stream);
+    if (p0) { hipEventRecord(ev.e[1], m->stream); hipStreamSynchronize(m->stream); }
+    if (p1) {
+        ev.e[2] = m->prof_get(); ev.e[3] = m->prof_get();
         hipStreamSynchronize(m->stream);
         hipEventRecord(ev.e[2], m->stream);
     }
     hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
                        d_matches, d_nmatches, match_cap, m->d_err);
-    if (m->prof_enabled) { hipEventRecord(ev.e[3], m->stream); hipStreamSynchronize(m->stream); m->prof_pending.push_back(ev); }
+    if (p1) { hipEventRecord(ev.e[3], m->stream); hipStreamSynchronize(m->stream); }
+    if (m->prof_enabled) m->prof_pending.push_back(ev);
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

@@ -348,6 +348,7 @@ long long aria_orb_slow_path_blocks(aria_orb_t h, int reset) {
 int aria_orb_set_profiling(aria_orb_t h, int enable) {
     if (!h) return ARIA_E_INVALID;
     h->prof.enabled = enable != 0;
+    h->prof.stage_mask = (enable & 1) ? ~0u : ((unsigned)enable >> 1);    // 1: every stage; else bit (s + 1) selects stage s
     return ARIA_OK;
 }
 

@@ -42,6 +42,8 @@ enum { STAGE_RESIZE = 0, STAGE_FAST_BLUR = 1, STAGE_SELECT = 2, STAGE_DESCRIBE =
 struct LaunchEvents { hipEvent_t start, stop; int stage; int launches; };
 struct Profiler {
     bool enabled = false;
+    unsigned stage_mask = ~0u;            // bit s: bracket stage s (every bracket drains the stream twice: ~20 us of idle GPU)
+    bool open = false;                    // a bracket is open
     std::vector<LaunchEvents> pending;    // recorded, not yet read
     std::vector<hipEvent_t> pool;         // recycled events
     double ms[STAGE_COUNT] = {0, 0, 0, 0};
@@ -59,7 +61,7 @@ struct Profiler {
 // Launch `kernel`; counted into the open stage when profiling is on.
 #define ARIA_LAUNCH(prof, kernel, grid, block, lds, st, ...)                       \
     do {                                                                           \
-        if ((prof) && (prof)->enabled) (prof)->count();                            \
+        if ((prof) && (prof)->open) (prof)->count();                               \
         hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);             \
     } while (0)
 

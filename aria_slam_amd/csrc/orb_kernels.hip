@@ -1152,13 +1152,15 @@ hipEvent_t Profiler::get() {
     return e;
 }
 void Profiler::begin(int stage, hipStream_t st) {
-    if (!enabled) return;
+    open = enabled && ((stage_mask >> stage) & 1u);
+    if (!open) return;
     cur = LaunchEvents{get(), get(), stage, 0};
     hipStreamSynchronize(st);
     hipEventRecord(cur.start, st);
 }
 void Profiler::end(hipStream_t st) {
-    if (!enabled) return;
+    if (!open) return;
+    open = false;
     hipEventRecord(cur.stop, st);
     hipStreamSynchronize(st);     // pin the stop marker to the end of this stage, not to whatever is queued next
     pending.push_back(cur);

@@ -118,8 +118,12 @@ class OrbHipExtractor:
 
     STAGES = ("resize", "fast_blur", "select", "describe")
 
-    def set_profiling(self, enable):
-        check(self._L.aria_orb_set_profiling(self._h, int(bool(enable))), "aria_orb_set_profiling")
+    def set_profiling(self, enable, stages=None):
+        """stages: optional subset of STAGES to bracket (each bracket drains the stream twice); default all."""
+        v = int(bool(enable))
+        if enable and stages is not None:
+            v = sum(1 << (self.STAGES.index(s) + 1) for s in stages)
+        check(self._L.aria_orb_set_profiling(self._h, v), "aria_orb_set_profiling")
 
     def get_profile(self, reset=True):
         """{stage: (total_ms, launches)}, frames -- HIP-event times on the launch stream."""
@@ -233,8 +237,11 @@ class HipMatcher:
 
     STAGES = ("knn2", "ratio_compact")
 
-    def set_profiling(self, enable):
-        check(self._L.aria_matcher_set_profiling(self._h, int(bool(enable))), "aria_matcher_set_profiling")
+    def set_profiling(self, enable, stages=None):
+        v = int(bool(enable))
+        if enable and stages is not None:
+            v = sum(1 << (self.STAGES.index(s) + 1) for s in stages)
+        check(self._L.aria_matcher_set_profiling(self._h, v), "aria_matcher_set_profiling")
 
     def get_profile(self, reset=True):
         ms = (C.c_double * 2)()

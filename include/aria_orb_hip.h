@@ -121,7 +121,10 @@ long long aria_orb_slow_path_blocks(aria_orb_t h, int reset);
 /* Per-stage device timing for bench.py's roofline figure (no reference counterpart): when enabled, HIP events
  * are recorded on the handle's stream around each stage of every internal pass.
  * Stages: 0 pyramid resize (7 launches per pass), 1 FAST+NMS+blur, 2 select (retainBest+Harris), 3 describe
- * (IC angle + rBRIEF). get_profile synchronises the stream; times are summed milliseconds since the last reset. */
+ * (IC angle + rBRIEF). get_profile synchronises the stream; times are summed milliseconds since the last reset.
+ * `enable`: 0 off; 1 every stage; any other even value brackets only the stages s whose bit (s + 1) is set (each
+ * bracket drains the stream before and after the stage, ~20 us of idle GPU, so a throughput run times only what it
+ * reports). The matcher's aria_matcher_set_profiling takes the same encoding over its 2 stages. */
 #define ARIA_ORB_STAGES 4
 int aria_orb_set_profiling(aria_orb_t h, int enable);
 int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms /*[4]*/, int64_t* stage_launches /*[4]*/,
