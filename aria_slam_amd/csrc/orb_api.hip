@@ -94,7 +94,7 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->D.blur, std::max<size_t>(mp.blur_frame_bytes * B, 256)));
     ARIA_HIP(hipMalloc(&h->D.cand, sizeof(uint32_t) * (size_t)mp.cand_frame_entries * B));
     ARIA_HIP(hipMalloc(&h->D.cand_cnt, sizeof(int) * kLevels * B));
-    ARIA_HIP(hipMalloc(&h->D.sel, sizeof(uint2) * (size_t)mp.sel_frame_entries * B));
+    ARIA_HIP(hipMalloc(&h->D.sel, sizeof(uint4) * (size_t)mp.sel_frame_entries * B));
     ARIA_HIP(hipMalloc(&h->D.sel_cnt, sizeof(int) * kLevels * B));
     ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
     h->bands_host.assign((size_t)((h->max_h + 7) / 8) * kLevels * 4 + 64, 0);

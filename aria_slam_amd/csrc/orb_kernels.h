@@ -26,7 +26,8 @@ struct DeviceScratch {
     uint8_t* blur;       // [max_batch][blur_frame_bytes]  pyramid levels 0..7, blurred
     uint32_t* cand;      // [max_batch][cand_frame_entries] FAST candidates x:11|y:11|score:8
     int* cand_cnt;       // [max_batch][8]
-    uint2* sel;          // [max_batch][sel_frame_entries]  (x | y<<16, harris bits), canonical order per level
+    uint4* sel;          // [max_batch][sel_frame_entries]  (x | y<<16, harris bits, rank in the canonical order of
+                         //   the level, -), stored per level in 64 x 64-px tile order (k_describe's cache locality)
     int* sel_cnt;        // [max_batch][8]
     uint32_t* tab;       // resize coefficient tables (ofs | c1 << 16)
     int* pyr_bands;      // [pyr_nbands][8][4] row ranges of the fused pyramid kernel

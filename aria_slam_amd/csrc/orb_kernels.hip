@@ -660,7 +660,7 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
 
 __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
-                                                uint2* __restrict__ sel, int* __restrict__ sel_cnt,
+                                                uint4* __restrict__ sel, int* __restrict__ sel_cnt,
                                                 int* __restrict__ err, unsigned long long* __restrict__ stamps) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     SSTAMP(0);
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     __shared__ int s_hist[256];
     __shared__ int s_misc[4];   // [0] threshold score, [1] n1, [2] n2
     __shared__ int s_wsum[4];
+    __shared__ int s_bin[1024];   // keypoints per tile of the level
 
     const int tid = threadIdx.x;
     const int l = blockIdx.x, frame = blockIdx.y;
@@ -814,12 +815,53 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         if (tid == 0) atomicOr(err, ERRBIT_SEL_OVERFLOW);
         n2 = g.sel_cap;
     }
-    uint2* out = sel + (int64_t)frame * P.sel_frame_entries + g.sel_off;
+    // Emit in raster order of 32 x 32-px tiles (counting sort, order inside a tile arbitrary), each record carrying its rank i in
+    // the canonical order: k_describe then works on spatially close keypoints at the same time -- their 37-row
+    // windows overlap, so the 128-byte lines they need are fetched from L2 once instead of once per keypoint --
+    // and writes keypoint i to row i of the output whatever order it was processed in.
+    uint4* out = sel + (int64_t)frame * P.sel_frame_entries + g.sel_off;
+    // 32-px tiles while the level has at most 1024 of them, else 64-px tiles
+    const int ts = (((g.w + 31) >> 5) * ((g.h + 31) >> 5) <= 1024) ? 5 : 6;
+    const int tiles_x = (g.w + (1 << ts) - 1) >> ts, n_bins = tiles_x * ((g.h + (1 << ts) - 1) >> ts);
+    for (int i = tid; i < n_bins; i += 256) s_bin[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const uint32_t xy = (uint32_t)s_keys[i];
+        atomicAdd(&s_bin[((xy >> (16 + ts)) * tiles_x) + ((xy & 0xFFFFu) >> ts)], 1);
+    }
+    __syncthreads();
+    {   // exclusive prefix sum of the bins: thread t owns bins 4t .. 4t+3
+        const int lane = tid & 63, wv = tid >> 6;
+        int b[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = (4 * tid + k < n_bins) ? s_bin[4 * tid + k] : 0; tot += b[k]; }
+        int c = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(c, d);
+            if (lane >= d) c += o;
+        }
+        __syncthreads();                      // s_wsum was read by the threshold scan above
+        if (lane == 63) s_wsum[wv] = c;
+        __syncthreads();
+        int run = c - tot;                    // exclusive within the wave
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+            if (w < wv) run += s_wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (4 * tid + k < n_bins) s_bin[4 * tid + k] = run;
+            run += b[k];
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < n2; i += 256) {
         const unsigned long long kk = s_keys[i];
         uint32_t u = ~(uint32_t)(kk >> 32);
         u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-        out[i] = make_uint2((uint32_t)kk, u);   // (x | y << 16, harris bits)
+        const uint32_t xy = (uint32_t)kk;
+        const int pos = atomicAdd(&s_bin[((xy >> (16 + ts)) * tiles_x) + ((xy & 0xFFFFu) >> ts)], 1);
+        out[pos] = make_uint4(xy, u, (uint32_t)i, 0u);   // (x | y << 16, harris bits, canonical rank)
     }
     if (tid == 0) sel_cnt[frame * kLevels + l] = n2;
     SSTAMP(5);
@@ -921,7 +963,7 @@ __device__ __forceinline__ int row16_sum(int v) {
 //   rBRIEF     : test 16*it + l16 for it = 0..15; one 64-bit ballot per iteration carries 16 descriptor bits for each
 //                of the four keypoints; lane l16 keeps word l16 and stores its two bytes
 __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
-                                                  const uint8_t* __restrict__ blur, const uint2* __restrict__ sel,
+                                                  const uint8_t* __restrict__ blur, const uint4* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err, int n_frames, int blocks_per_frame,
@@ -957,10 +999,11 @@ __global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint
     const int nk = min(4, cnt[l] - i0);                                // valid keypoints of this wave
     if (nk <= 0) return;
     const bool valid = grp < nk;
-    const int oidx = base + i0 + grp;
+    // slots hold the level's keypoints in tile order; the record says which row of the output it is
+    const uint4 sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
+    const int oidx = base + (int)sv.z;
     const bool fits = oidx < kp_cap;
     if (valid && !fits && l16 == 0) atomicOr(err, ERRBIT_KPCAP);
-    const uint2 sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
     const int x = sv.x & 0xFFFF, y = sv.x >> 16;
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     DSTAMP(1);
