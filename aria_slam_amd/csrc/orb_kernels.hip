@@ -935,7 +935,8 @@ __device__ __forceinline__ int wave_sum(int v) {
 constexpr int kDescR = 18;
 constexpr int kDescRows = 2 * kDescR + 1;   // 37
 constexpr int kDescPitch = 64;              // four 16-byte-ALIGNED pieces per row (>= 37 + 15 bytes of alignment slack)
-constexpr int kDescKp = 8;                  // keypoints per 128-thread workgroup: 2 waves x 4 DPP rows
+constexpr int kDescWaves = 2;                // waves per workgroup (4 measured slightly slower); consecutive slots are spatially close
+constexpr int kDescKp = 4 * kDescWaves;     // keypoints per workgroup: 4 DPP rows per wave
 constexpr int kIcPitch = 48;                // raw window: 31 rows x three 16-byte pieces (>= 31 + 3 bytes of alignment slack)
 struct __attribute__((packed, aligned(4))) DwordQuad { uint32_t a, b, c, d; };   // 16-byte load from a 4-byte-aligned address
 
@@ -962,14 +963,14 @@ __device__ __forceinline__ int row16_sum(int v) {
 //   IC moments : columns u = 2*l16-15, 2*l16-14 over the 31 rows of the disc, DPP row reduction
 //   rBRIEF     : test 16*it + l16 for it = 0..15; one 64-bit ballot per iteration carries 16 descriptor bits for each
 //                of the four keypoints; lane l16 keeps word l16 and stores its two bytes
-__global__ __launch_bounds__(128) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint4* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err, int n_frames, int blocks_per_frame,
                                                   unsigned long long* __restrict__ stamps) {
     // diagnostic only (ARIA_DESC_STAMPS=1): s_memtime at the phase boundaries of every wave
-#define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * kDescWaves + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     DSTAMP(0);
     // One LDS window per keypoint, used twice: first the raw 31 x 48 window (IC moments), then -- once the moments are
     // reduced -- the blurred 37 x 64 window, which has been waiting in registers since both were requested together.
@@ -1320,11 +1321,11 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         static unsigned long long* d_stamps = nullptr;     // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
         static int want_stamps = -1;
         if (want_stamps < 0) { const char* e = getenv("ARIA_DESC_STAMPS"); want_stamps = (e && e[0] == '1') ? 1 : 0; }
-        const size_t nwaves = (size_t)bpf * frames8 * 2;
+        const size_t nwaves = (size_t)bpf * frames8 * kDescWaves;
         if (want_stamps && !d_stamps && nwaves <= (1u << 22)) hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * (1u << 22));
         unsigned long long* stp = (want_stamps && nwaves <= (1u << 22)) ? d_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
-        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(128), 0, st, P, S, D.raw, D.blur,
+        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
                     D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp);
         if (stp) {
             hipStreamSynchronize(st);
