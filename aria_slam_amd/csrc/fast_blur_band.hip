@@ -73,6 +73,7 @@ __device__ __forceinline__ uint32_t umad24(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
 }
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                                                         uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
                                                         int* __restrict__ cand_cnt, int* __restrict__ err, int l,
                                                         int nb, int qcap, int ablate, unsigned long long* __restrict__ stamps,
-                                                        int* __restrict__ slow_blocks) {
+                                                        int* __restrict__ slow_blocks, const uint32_t* __restrict__ tab,
+                                                        uint8_t* __restrict__ raw_next) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_qn, s_ovf;
     // diagnostic build only (ARIA_STAMPS=1): phase boundaries of wave 0 of every workgroup, s_memtime ticks
@@ -309,6 +311,70 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                 }
             }
         }
+
+        // ---- a6.1 fused: this workgroup also produces the rows of level l+1 whose upper source row it owns, from the
+        //      level-l rows it has staged (the bilinear resize needs rows oy, oy+1 <= y0 + RB, inside the halo), with
+        //      the arithmetic of k_resize_lds<true> (v_perm + v_dot2_u32_u16; same integers). The separate resize pass
+        //      and its re-read of level l from HBM disappear. A lane keeps the x-table words of its output dword in
+        //      registers and walks the band's ~RB/1.2 output rows; oy is monotone in dy, so the candidate rows are
+        //      bracketed arithmetically and the y table decides ownership exactly. ----
+        if (raw_next != nullptr) {
+            const LevelGeom gn = P.lv[l + 1];
+            const int groups_n = gn.pitch >> 2;
+            uint8_t* dstl = raw_next + (int64_t)frame * P.raw_frame_bytes + gn.raw_off;
+            const uint32_t* xt = tab + gn.xtab;
+            const uint32_t* yt = tab + gn.ytab;
+            const int y_end = min(y0 + RB, h);
+            const int dlo = max((int)(((int64_t)y0 * gn.h) / h) - 2, 0);
+            const int dhi = min((int)(((int64_t)y_end * gn.h + h - 1) / h) + 2, gn.h);
+            constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
+            for (int gx = li; gx < groups_n; gx += lpr) {
+                const int dx0 = gx * 4;
+                uint32_t xw[4], xo[4], xs[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t t = xt[min(dx0 + i, gn.w - 1)];
+                    const uint32_t ox = t & 0xFFFFu, cx1 = t >> 16;
+                    xw[i] = (256u - cx1) | (cx1 << 16);
+                    xo[i] = (ox & ~3u) + 4u;                            // staged column 0 is x = -4
+                    xs[i] = 0x0C010C00u + (ox & 3u) * 0x00010001u;
+                }
+                // y-table words of a batch of candidate rows are fetched together (one global round trip per 16 rows,
+                // not one per row)
+                for (int d0 = dlo + sb; d0 < dhi; d0 += 16 * nb) {
+                uint32_t tyv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) tyv[k] = yt[min(d0 + k * nb, gn.h - 1)];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int dy = d0 + k * nb;
+                    const uint32_t ty = tyv[k];
+                    const int oy = ty & 0xFFFF;
+                    if (dy >= dhi || oy < y0 || oy >= y_end) continue;  // past the bracket / another workgroup's row
+                    uint32_t outw = 0;
+                    if (dx0 < gn.w) {
+                        const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
+                        const uint8_t* rowa = s_pix + (oy - y0 + 4) * pitchL;
+                        const uint8_t* rowb = s_pix + (min(oy + 1, h - 1) - y0 + 4) * pitchL;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xo[i]);
+                            const uint32_t* qb = reinterpret_cast<const uint32_t*>(rowb + xo[i]);
+                            const uint32_t top = __builtin_amdgcn_perm(qa[1], qa[0], xs[i]);     // p00 | p01 << 16
+                            const uint32_t bot = __builtin_amdgcn_perm(qb[1], qb[0], xs[i]);
+                            const us2v wx = __builtin_bit_cast(us2v, xw[i]);
+                            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, top), wx, 0u, false);
+                            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, bot), wx, 0u, false);
+                            const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, h0 | (h1 << 16)),
+                                                                      __builtin_bit_cast(us2v, cyp), 32768u, false);   // < 2^24
+                            outw = __builtin_amdgcn_perm(v, outw, put[i]);
+                        }
+                    }
+                    *reinterpret_cast<uint32_t*>(dstl + (int64_t)dy * gn.pitch + dx0) = outw;
+                }
+                }
+            }
+        }
     }
     STAMP(2);
     __syncthreads();
@@ -444,7 +510,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
 }
 
 void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
-                           Profiler* prof) {
+                           Profiler* prof, bool fuse_resize) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -488,7 +554,8 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
         if (use_side && l > 0) hipStreamWaitEvent(s, ev_fork, 0);
         unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
 #define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
-                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1)
+                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1, D.tab, \
+                                         (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr)
         if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
         else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
 #undef ARIA_FB_LAUNCH

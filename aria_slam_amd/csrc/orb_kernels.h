@@ -67,8 +67,10 @@ struct Profiler {
     } while (0)
 
 // band implementation of the FAST+NMS+blur stage (fast_blur_band.hip): 8 launches, one per level
+// fuse_resize: every level's launch also writes the raw rows of the next level (the caller then skips the resize pass;
+// the launches must stay in level order on one stream)
 void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
-                           Profiler* prof);
+                           Profiler* prof, bool fuse_resize);
 int fast_blur_impl();   // 1 = band (default), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
 
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,

@@ -1239,6 +1239,16 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
 
     // ---- a6.1 pyramid ----
+    // Default: no pass of its own -- the FAST/blur launch of level l writes the raw rows of level l+1 from the rows it
+    // has staged (fast_blur_band.hip). A separate pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL,
+    // ARIA_PYRAMID_IMPL) or when the band kernel is not the one in use (tile kernel, per-level side streams).
+    static const bool fuse_resize = [] {
+        const char* f = getenv("ARIA_RESIZE_FUSE");
+        const char* ls = getenv("ARIA_LEVEL_STREAMS");
+        return fast_blur_impl() == 1 && !(f && f[0] == '0') && !getenv("ARIA_RESIZE_IMPL") && !getenv("ARIA_PYRAMID_IMPL") &&
+               !(ls && ls[0] == '1');
+    }();
+    if (!fuse_resize) {
     if (prof) prof->begin(STAGE_RESIZE, st);
     static int pyr_impl = -1;   // 0 = one resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
                                 // measured slower at 640x480: the top-down halo makes small bands recompute too much)
@@ -1273,11 +1283,12 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     }
 
     if (prof) prof->end(st);
+    }
 
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
     if (fast_blur_impl() == 1) {
-        launch_fast_blur_band(P, S, D, n_frames, st, prof);
+        launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize);
     } else {
         ARIA_LAUNCH(prof, k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur,
                     D.cand, D.cand_cnt, D.err);
