@@ -221,7 +221,10 @@ def main():
         p0 = W * H
         lv = ext.level_info(W, H)
         p7 = lv[7][0] * lv[7][1]
-        alg = {"resize": (P - p7) + (P - p0), "fast_blur": 2 * P, "describe": 56 * NF}
+        # pyramid fused into the FAST/blur launches (default): that kernel also writes the raw levels 1..7 (P - p0 bytes);
+        # it reads each level once either way
+        fused_pyramid = prof_e_all["resize"][1] == 0
+        alg = {"resize": (P - p7) + (P - p0), "fast_blur": 2 * P + ((P - p0) if fused_pyramid else 0), "describe": 56 * NF}
         all_ms = {k: v[0] for k, v in prof_e_all.items()}
         all_ms.update({k: v[0] for k, v in prof_m_all.items()})
         dom = max(("resize", "fast_blur", "select", "describe"), key=lambda k: all_ms[k])
@@ -232,7 +235,9 @@ def main():
         traffic_pf, traffic_src = load_traffic(args.chunk)
         ext_ms = sum(all_ms[k] for k in ("resize", "fast_blur", "select", "describe")) * (prof_frames / max(frames_all, 1))
         roofline = {
-            "bound": "hbm", "kernel": "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level, fused; 8 level launches per pass)",
+            "bound": "hbm", "kernel": "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level + bilinear resize to the next level, "
+                                      "fused; 8 level launches per pass)" if fused_pyramid else
+                                      "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level, fused; 8 level launches per pass)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": (int(traffic_pf * frames_per_launch) if traffic_pf and (W, H, NF) == (640, 480, 2000) else None),
