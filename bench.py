@@ -101,7 +101,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--chunk", type=int, default=1024, help="frames per internal extractor pass")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="frames per internal extractor pass (scratch is sized for it: ~3.5 MB per 640x480 frame); "
+                         "0 = the whole per-GPU sequence, at most 8192 -- with 288 GB of HBM one pass per step is the "
+                         "cheapest (1024: 216k, 2048: 222k, 4096: 225k, 8192: 230k frames/s)")
     ap.add_argument("--ratio", type=float, default=0.75)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -133,6 +136,8 @@ def main():
     A.load_library()
     W, H, NF = args.width, args.height, args.features
     B = 2 * args.pairs
+    if args.chunk <= 0:
+        args.chunk = min(B, 8192)
 
     # ---- synthetic sequence shard of this rank, resident in HBM before timing ----
     host = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=False)
