@@ -610,10 +610,11 @@ __global__ __launch_bounds__(256) void k_fast_blur(Plan P, FrameSrc S, const uin
 // ------------------------------------------------------------------------------------------------------
 // a6.3-a6.5  one workgroup per (frame, level)
 // ------------------------------------------------------------------------------------------------------
-// orb.cpp HarrisResponses(blockSize 7, k 0.04f). The 9x9 neighbourhood is fetched as 3 aligned dwords per row
-// (27 loads) instead of 81 byte gathers -- scattered byte loads are texture-path bound -- and the 9 bytes of a row
-// are cut out of the 12-byte window with v_alignbyte. dword_ok = the level's rows are 4-byte aligned.
-__device__ __forceinline__ void harris_row9(const uint8_t* rowp, int xs, int sh, bool dword_ok, int* out9) {
+// One 9-pixel row of the Harris neighbourhood as five int16 pairs E[k] = (p[2k], p[2k+1]) (E[4] = (p[8], 0)): the row is
+// fetched as 3 aligned dwords (scattered byte loads are texture-path bound), cut out with v_alignbyte and widened with
+// v_perm. dword_ok = the level's rows are 4-byte aligned.
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void harris_row_pairs(const uint8_t* rowp, int xs, int sh, bool dword_ok, uint32_t* E) {
     uint32_t w0, w1, w2;
     if (dword_ok) {
         const uint32_t* q = reinterpret_cast<const uint32_t*>(rowp + xs);
@@ -626,31 +627,52 @@ __device__ __forceinline__ void harris_row9(const uint8_t* rowp, int xs, int sh,
     }
     const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh);   // bytes sh .. sh+3   = columns 0..3
     const uint32_t b = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)sh);   // bytes sh+4 .. sh+7 = columns 4..7
-    out9[0] = a & 0xFF; out9[1] = (a >> 8) & 0xFF; out9[2] = (a >> 16) & 0xFF; out9[3] = a >> 24;
-    out9[4] = b & 0xFF; out9[5] = (b >> 8) & 0xFF; out9[6] = (b >> 16) & 0xFF; out9[7] = b >> 24;
-    out9[8] = (w2 >> (8 * sh)) & 0xFF;                                      // byte sh+8          = column 8
+    E[0] = __builtin_amdgcn_perm(0u, a, 0x0c010c00u);
+    E[1] = __builtin_amdgcn_perm(0u, a, 0x0c030c02u);
+    E[2] = __builtin_amdgcn_perm(0u, b, 0x0c010c00u);
+    E[3] = __builtin_amdgcn_perm(0u, b, 0x0c030c02u);
+    E[4] = (w2 >> (8 * sh)) & 0xFFu;                                        // byte sh+8 = column 8
 }
 
+__device__ __forceinline__ uint32_t pk16_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) + __builtin_bit_cast(s2v, b));
+}
+__device__ __forceinline__ uint32_t pk16_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b));
+}
+
+// orb.cpp HarrisResponses(blockSize 7, k 0.04f): integer Sobel sums a = sum Ix^2, b = sum Iy^2, c = sum Ix Iy over the
+// 7 x 7 block, then the float formula. Separable and two columns per op in packed int16 (|Ix|, |Iy| <= 1020):
+//   s = p[y-1] + 2 p[y] + p[y+1],  Ix[j] = s[j+1] - s[j-1];   d = p[y+1] - p[y-1],  Iy[j] = d[j-1] + 2 d[j] + d[j+1]
+// with the even-aligned pairs E[k] = (col 2k, 2k+1) and the odd-aligned O[k] = (col 2k+1, 2k+2) cut out of them by
+// v_alignbit; the products are accumulated two at a time by v_dot2_i32_i16. Same integers as the scalar form.
 __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, int x, int y, bool dword_ok) {
     int a = 0, b = 0, c = 0;
     const int xs = (x - 4) & ~3, sh = (x - 4) & 3;
     const uint8_t* base = img + (int64_t)(y - 4) * pitch;
-    int prev[9], cur[9], nxt[9];
-    harris_row9(base, xs, sh, dword_ok, prev);
-    harris_row9(base + pitch, xs, sh, dword_ok, cur);
+    uint32_t R[9][5];
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        harris_row9(base + (int64_t)(i + 2) * pitch, xs, sh, dword_ok, nxt);
+    for (int r = 0; r < 9; r++) harris_row_pairs(base + (int64_t)r * pitch, xs, sh, dword_ok, R[r]);
 #pragma unroll
-        for (int j = 1; j <= 7; j++) {
-            const int Ix = (cur[j + 1] - cur[j - 1]) * 2 + (prev[j + 1] - prev[j - 1]) + (nxt[j + 1] - nxt[j - 1]);
-            const int Iy = (nxt[j] - prev[j]) * 2 + (nxt[j - 1] - prev[j - 1]) + (nxt[j + 1] - prev[j + 1]);
-            a += Ix * Ix;
-            b += Iy * Iy;
-            c += Ix * Iy;
+    for (int i = 1; i <= 7; i++) {
+        uint32_t sE[5], dE[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            sE[k] = pk16_add(pk16_add(R[i - 1][k], R[i + 1][k]), pk16_add(R[i][k], R[i][k]));
+            dE[k] = pk16_sub(R[i + 1][k], R[i - 1][k]);
         }
 #pragma unroll
-        for (int j = 0; j < 9; j++) { prev[j] = cur[j]; cur[j] = nxt[j]; }
+        for (int k = 0; k < 4; k++) {
+            // columns j = 2k+1, 2k+2 (the pair k = 3 holds j = 7 and a column-8 term that is masked off)
+            uint32_t ix = pk16_sub(sE[k + 1], sE[k]);                                   // s[j+1] - s[j-1]
+            const uint32_t dO = __builtin_amdgcn_alignbit(dE[k + 1], dE[k], 16);        // (d[2k+1], d[2k+2])
+            uint32_t iy = pk16_add(pk16_add(dE[k], dE[k + 1]), pk16_add(dO, dO));       // d[j-1] + 2 d[j] + d[j+1]
+            if (k == 3) { ix &= 0xFFFFu; iy &= 0xFFFFu; }
+            const s2v vx = __builtin_bit_cast(s2v, ix), vy = __builtin_bit_cast(s2v, iy);
+            a = __builtin_amdgcn_sdot2(vx, vx, a, false);
+            b = __builtin_amdgcn_sdot2(vy, vy, b, false);
+            c = __builtin_amdgcn_sdot2(vx, vy, c, false);
+        }
     }
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
