@@ -431,3 +431,58 @@ def test_survivor_queue_self_tunes_on_corner_dense_images(aria, oracle):
         assert e.slow_path_blocks() == 0
     finally:
         e.close()
+
+
+def test_profiling_stage_masks(aria, torch_cuda):
+    """aria_orb_set_profiling / aria_matcher_set_profiling: 1 brackets every stage, an even value only the stages
+    whose bit (s + 1) is set; unbracketed stages report 0 ms and 0 launches; results do not depend on profiling."""
+    torch = torch_cuda
+    W, H, NF, B = 640, 480, 1000, 4
+    seq = aria.synth_sequence(77, 2, W, H)[:B]
+    dev = torch.device("cuda", 0)
+    images = torch.from_numpy(seq).to(dev)
+    e = aria.OrbHipExtractor(max_features=NF, max_width=W, max_height=H, max_batch=B)
+    m = aria.HipMatcher()
+    try:
+        cap = e.kp_capacity()
+        kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+        matches = torch.zeros((B, cap, 12), dtype=torch.uint8, device=dev)
+        nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def run():
+            e.extract_batch_device(images, B, W, H, kps, desc, counts, cap)
+            e.check()
+            m.match_batch_device(desc.data_ptr() + cap * 32, counts.data_ptr() + 4, desc, counts, B - 1, cap * 32, 0.75,
+                                 matches, nm, cap)
+            m.sync()
+            return desc.cpu().numpy().copy(), nm.cpu().numpy().copy()
+
+        ref = run()
+        e.set_profiling(True, stages=["fast_blur"])
+        m.set_profiling(True, stages=["knn2"])
+        got = run()
+        pe, frames = e.get_profile()
+        pm, pairs = m.get_profile()
+        assert frames == B and pairs == B - 1
+        assert pe["fast_blur"][0] > 0 and pe["fast_blur"][1] == 8
+        assert all(pe[s] == (0.0, 0) for s in ("resize", "select", "describe"))
+        assert pm["knn2"][0] > 0 and pm["knn2"][1] == 1 and pm["ratio_compact"] == (0.0, 0)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        e.set_profiling(True)
+        m.set_profiling(True)
+        run()
+        pe, _ = e.get_profile()
+        pm, _ = m.get_profile()
+        assert pe["select"][1] == 1 and pe["describe"][1] == 1 and pe["fast_blur"][1] == 8
+        assert pe["resize"][1] in (0, 7)          # 0: pyramid fused into the FAST/blur launches (default)
+        assert pm["ratio_compact"][1] == 1
+        e.set_profiling(False)
+        m.set_profiling(False)
+        run()
+        assert e.get_profile()[1] == 0
+    finally:
+        e.close()
+        m.close()
