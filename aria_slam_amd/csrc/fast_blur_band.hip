@@ -28,7 +28,8 @@
 
 namespace aria {
 
-constexpr int kBandR = 12;                 // output rows per strip (one lane walks R + 8 staged rows)
+constexpr int kBandR = 13;                 // output rows per strip: R + 8 = 21 staged rows = exactly three 7-row groups of the lane walk
+                                           // (12: 2.28, 13: 2.26, 20: 2.33, 32: 3.1 us/frame)
 constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a strip
 
 // Workgroup geometry for a level of width w: NB vertically stacked strips of R rows share one staged block of
