@@ -27,7 +27,7 @@ struct aria_orb_s {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 0;
-    int band_qpct0 = 15;            // survivor-queue size of the band kernel at level 0 (% of a workgroup's pixels); self-tuned
+    int band_qpct0 = 10;            // survivor-queue size of the band kernel at level 0 (% of a workgroup's pixels); self-tuned
     long long slow_blocks = 0;      // band-kernel workgroups that overflowed their queue since the last reset
 
     Plan plan{};            // plan of the most recent (width, height)

@@ -59,8 +59,8 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
     P->nfeatures = nfeatures;
     P->tie_mode = tie_mode;
     P->fast_threshold = kFastThreshold;
-    P->band_qpct0 = 15;
-    P->band_qstep = 5;
+    P->band_qpct0 = 10;
+    P->band_qstep = 4;
     P->band_budget_kb = 24;
 
     // orb.cpp computeKeyPoints: nfeaturesPerLevel
