@@ -160,7 +160,9 @@ class OrbHipExtractor:
 
 
 class HipMatcher:
-    """Replaces aria::adapters::gpu::CudaMatcher (reference include/adapters/gpu/CudaMatcher.hpp)."""
+    """Replaces aria::adapters::gpu::CudaMatcher (reference include/adapters/gpu/CudaMatcher.hpp).
+    stream: a real hipStream_t handle to borrow; None or 0 (torch's default stream) makes the handle create its own
+    stream, which is NOT ordered against other handles' streams -- share one explicit stream, or sync in between."""
 
     def __init__(self, stream=None, device=0, max_query=4096, max_train=4096):
         self._L = _lib.load_library()

@@ -145,7 +145,13 @@ def main():
     images = host.to(dev)
     del host
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # One explicit (non-null) stream for everything in a step: torch's default stream has handle 0, which both C-ABI
+    # handles read as "no stream given, create your own" -- extractor and matcher would then run on two unordered
+    # streams and the matcher could start before the frames it reads are described.
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
+    assert stream != 0
     ext = A.OrbHipExtractor(max_features=NF, stream=stream, device=dev.index, max_width=W, max_height=H,
                             max_batch=args.chunk)
     mat = A.HipMatcher(stream=stream, device=dev.index, max_query=4096, max_train=4096)
@@ -230,6 +236,8 @@ def main():
         # it reads each level once either way
         fused_pyramid = prof_e_all["resize"][1] == 0
         alg = {"resize": (P - p7) + (P - p0), "fast_blur": 2 * P + ((P - p0) if fused_pyramid else 0), "describe": 56 * NF}
+        if os.environ.get("ARIA_BENCH_DEBUG"):
+            print("timed:", prof_e, prof_frames, prof_m, prof_pairs, "extra:", prof_e_all, frames_all, prof_m_all, pairs_all, file=sys.stderr)
         all_ms = {k: v[0] for k, v in prof_e_all.items()}
         all_ms.update({k: v[0] for k, v in prof_m_all.items()})
         dom = max(("resize", "fast_blur", "select", "describe"), key=lambda k: all_ms[k])

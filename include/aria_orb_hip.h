@@ -60,7 +60,10 @@ typedef struct aria_matcher_s* aria_matcher_t;
 typedef struct {
     int   struct_size;     /* = sizeof(aria_orb_config)                                                     */
     int   device;          /* HIP device ordinal                                                            */
-    void* stream;          /* borrowed hipStream_t, or NULL                                                 */
+    void* stream;          /* borrowed hipStream_t, or NULL = the handle creates (and owns) a stream. The legacy
+                            * default stream has handle 0 and therefore cannot be borrowed: two handles that must run
+                            * in order (extract, then match on its descriptors) need one real stream between them,
+                            * or a sync (aria_orb_check) in between.                                            */
     int   max_width;       /* largest image the handle must accept                                          */
     int   max_height;
     int   max_features;    /* nfeatures (OrbCudaExtractor.hpp:12 default 1000)                              */
