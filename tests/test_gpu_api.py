@@ -148,7 +148,9 @@ def test_batch_device_equals_per_frame_and_chunks(aria, torch_cuda):
     B = 2 * n_pairs
     dev = torch.device("cuda", 0)
     images = torch.from_numpy(seq).to(dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    work = torch.cuda.Stream(device=dev)           # a real stream to borrow (torch's default stream has handle 0 = "none")
+    stream = work.cuda_stream
+    torch.cuda.synchronize()
     single = _ext(aria)
     per_frame = [single.extract(seq[i]) for i in range(B)]
     single.close()

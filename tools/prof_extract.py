@@ -25,7 +25,9 @@ def main():
     host = torch.empty((B, a.height, a.width), dtype=torch.uint8)
     A.synth_sequence(1, a.pairs, a.width, a.height, out=host.numpy())
     images = host.to(dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    work = torch.cuda.Stream(device=dev)          # one real stream for both handles (handle 0 would give each its own)
+    torch.cuda.set_stream(work)
+    stream = work.cuda_stream
     ext = A.OrbHipExtractor(max_features=a.features, stream=stream, max_width=a.width, max_height=a.height, max_batch=a.chunk)
     mat = A.HipMatcher(stream=stream)
     cap = ext.kp_capacity()
