@@ -107,3 +107,20 @@ def test_knn2_random_sets_with_ties(aria, oracle, nq, nt):
             assert got.tobytes() == want.tobytes()
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("w,h,nf", [(2047, 2047, 3000), (1919, 1083, 1500), (96, 2047, 200)])
+def test_extract_bit_exact_large_and_limit_sizes(aria, oracle, w, h, nf):
+    """The image-size limit of the candidate packing (2047 x 2047: widest staged rows, 32 x 32 selection tiles of 64 px),
+    an odd HD-like size and a tall narrow strip, against the oracle."""
+    a, _ = aria.synth_frame_pair(11, w, h)
+    e = aria.OrbHipExtractor(max_features=nf, max_width=w, max_height=h)
+    try:
+        f = e.extract(a)
+        kps, desc = oracle.orb_extract(a, oracle.default_params(nf))
+        assert len(f["keypoints"]) == len(kps)
+        assert f["keypoints"].tobytes() == kps.tobytes(), "keypoint records differ"
+        assert np.array_equal(f["descriptors"], desc), "descriptors differ"
+        assert e.slow_path_blocks() >= 0
+    finally:
+        e.close()
