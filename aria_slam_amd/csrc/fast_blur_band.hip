@@ -413,6 +413,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
         if (cb) s_corner[base + __popcll(ma) + __popcll(mb & lt)] = eb | ((uint32_t)sb2 << 24);
         __syncthreads();
     }
+    STAMP(4);
     const int cn = ovf ? 0 : s_cn;
     if (!ovf) {
         // the staged pixels are dead: reuse their LDS as the score map (rows ro = 0 .. RB+1, columns x+1)
@@ -568,7 +569,7 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
             hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
             double ph[7] = {0};
             for (size_t b = 0; b < nblk; b++) for (int k = 0; k < 7; k++) ph[k] += (double)(hs[b * 8 + k + 1] - hs[b * 8 + k]);
-            fprintf(stderr, "[stamps L%d] blocks %zu ticks(100MHz): stage %.0f main %.0f barrier %.0f score %.0f map %.0f nms %.0f out %.0f\n",
+            fprintf(stderr, "[stamps L%d] blocks %zu, cycles: stage %.0f main+pyramid %.0f barrier %.0f score %.0f map %.0f nms %.0f out %.0f\n",
                     l, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, ph[4] / nblk, ph[5] / nblk, ph[6] / nblk);
         }
     }
