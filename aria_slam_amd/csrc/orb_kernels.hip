@@ -800,14 +800,17 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     for (int i = n1 + tid; i < np; i += 256) s_keys[i] = ~0ull;
     __syncthreads();
     // bitonic sort, ascending on (~harris_order, y, x) == Harris descending, then y, then x
-    // Thread t of a step owns the pair (i0, i0 | j); for j <= 64 the 64 threads of a wave own one aligned block of 128
-    // keys and every partner stays inside it, so those steps need no workgroup barrier -- the wave's LDS accesses are
-    // served in order. Of the 55 steps of a 1024-key sort only the 6 with j >= 128 (and the steps next to them)
-    // synchronise the workgroup.
+    // Bitonic sort. Steps are taken two at a time: a thread loads the four keys (i, i+h, i+2h, i+3h) of a radix-4
+    // butterfly, does the compare-exchanges of step j = 2h and of step h in registers and stores them back -- one LDS
+    // round trip per two steps. (When a merge phase k has an odd number of steps its first one, j = k/2, goes alone, two
+    // pairs per thread, between workgroup barriers.) In butterfly steps a wave owns one aligned block of 256 keys; while
+    // consecutive butterflies stay inside it (span 2j <= 256) no workgroup barrier is needed -- the wave's LDS
+    // accesses are served in order.
+    auto steps_of = [](int kk) { int n = 0; for (int jj = kk >> 1; jj > 0; jj >>= 1) n++; return n; };
     for (int k = 2; k <= np; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            // two pairs per thread and trip, all four keys requested before the first compare: one LDS round trip
-            // per step instead of one per pair
+        int j = k >> 1;
+        if (steps_of(k) & 1) {
+            __syncthreads();
             for (int t0 = tid; t0 < (np >> 1); t0 += 512) {
                 const int ta = t0, tb = t0 + 256;
                 const bool hb = tb < (np >> 1);
@@ -817,8 +820,26 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
                 if ((xa > ya) == ((a0 & k) == 0)) { s_keys[a0] = ya; s_keys[a1] = xa; }
                 if (hb && (xb > yb) == ((b0 & k) == 0)) { s_keys[b0] = yb; s_keys[b1] = xb; }
             }
-            const int next_j = j > 1 ? (j >> 1) : k;     // first step of the next k is j = k
-            if (j >= 128 || next_j >= 128) __syncthreads();
+            __syncthreads();
+            j >>= 1;
+        }
+        for (; j > 1; j >>= 2) {
+            const int h = j >> 1;
+            for (int t = tid; t < (np >> 2); t += 256) {
+                const int i = ((t & ~(h - 1)) << 2) | (t & (h - 1));
+                unsigned long long e0 = s_keys[i], e1 = s_keys[i + h], e2 = s_keys[i + j], e3 = s_keys[i + j + h];
+                const bool up = (i & k) == 0;
+                unsigned long long tmp;
+                if ((e0 > e2) == up) { tmp = e0; e0 = e2; e2 = tmp; }       // step j
+                if ((e1 > e3) == up) { tmp = e1; e1 = e3; e3 = tmp; }
+                if ((e0 > e1) == up) { tmp = e0; e0 = e1; e1 = tmp; }       // step h
+                if ((e2 > e3) == up) { tmp = e2; e2 = e3; e3 = tmp; }
+                s_keys[i] = e0; s_keys[i + h] = e1; s_keys[i + j] = e2; s_keys[i + j + h] = e3;
+            }
+            // what follows: a butterfly with top step j/4 of this phase, or the next phase (a butterfly with top step k
+            // if it has an even number of steps; a single step syncs for itself)
+            const int next_span = (j >> 2) > 1 ? 2 * (j >> 2) : ((k < np && !(steps_of(2 * k) & 1)) ? 2 * k : 0);
+            if (2 * j > 256 || next_span > 256 || np > 1024) __syncthreads();   // np > 1024: a thread makes several trips
             else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
         }
     }
