@@ -107,6 +107,8 @@ def main():
                          "cheapest (1024: 216k, 2048: 222k, 4096: 225k, 8192: 230k frames/s)")
     ap.add_argument("--ratio", type=float, default=0.75)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="extractor and matcher on one stream (default: matcher of step s beside the extractor of step s+1)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -145,33 +147,63 @@ def main():
     images = host.to(dev)
     del host
 
-    # One explicit (non-null) stream for everything in a step: torch's default stream has handle 0, which both C-ABI
-    # handles read as "no stream given, create your own" -- extractor and matcher would then run on two unordered
-    # streams and the matcher could start before the frames it reads are described.
-    work_stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(work_stream)
-    stream = work_stream.cuda_stream
-    assert stream != 0
-    ext = A.OrbHipExtractor(max_features=NF, stream=stream, device=dev.index, max_width=W, max_height=H,
+    # Streams. torch's default stream has handle 0, which both C-ABI handles read as "no stream given, create your
+    # own": never pass it. The extractor runs on stream E, the matcher on stream M, with two sets of output buffers:
+    # M matches step s (it waits for E's "set s&1 described" event) while E already extracts step s+1 into the other
+    # set (it waits for M's "set matched" event of two steps ago before overwriting). k_fast_blur_band is VALU-issue
+    # bound and k_knn2_mfma lives on the matrix pipe, so the two overlap well (+6 %, tools/overlap_probe.py; same
+    # results). --no-pipeline puts both handles on one stream.
+    se = torch.cuda.Stream(device=dev)
+    sm = torch.cuda.Stream(device=dev) if args.pipeline else se
+    torch.cuda.set_stream(se)
+    assert se.cuda_stream != 0 and sm.cuda_stream != 0
+    ext = A.OrbHipExtractor(max_features=NF, stream=se.cuda_stream, device=dev.index, max_width=W, max_height=H,
                             max_batch=args.chunk)
-    mat = A.HipMatcher(stream=stream, device=dev.index, max_query=4096, max_train=4096)
+    mat = A.HipMatcher(stream=sm.cuda_stream, device=dev.index, max_query=4096, max_train=4096)
     cap = ext.kp_capacity()
-    kps = torch.empty((B, cap, 24), dtype=torch.uint8, device=dev)
-    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+    dstride = cap * 32
+    sets = []
+    for _ in range(2 if args.pipeline else 1):
+        sets.append(dict(kps=torch.empty((B, cap, 24), dtype=torch.uint8, device=dev),
+                         desc=torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                         counts=torch.zeros((B,), dtype=torch.int32, device=dev),
+                         matches=torch.empty((B, cap, 12), dtype=torch.uint8, device=dev),
+                         nmatches=torch.zeros((B,), dtype=torch.int32, device=dev),
+                         described=torch.cuda.Event(), matched=torch.cuda.Event()))
+    # the frame before this rank's range (shard.py: the halo frame): its descriptors are the train set of frame 0's
+    # match; extracted once, outside the timed region
     halo_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
     halo_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
-    matches = torch.empty((B, cap, 12), dtype=torch.uint8, device=dev)
-    nmatches = torch.zeros((B,), dtype=torch.int32, device=dev)
-    dstride = cap * 32
+    step_no = [0]
 
-    def step():
-        halo_desc.copy_(desc[B - 1])
-        halo_cnt.copy_(counts[B - 1:B])
-        ext.extract_batch_device(images, B, W, H, kps, desc, counts, cap)
-        mat.match_batch_device(desc, counts, halo_desc, halo_cnt, 1, dstride, args.ratio, matches, nmatches, cap)
-        mat.match_batch_device(desc.data_ptr() + dstride, counts.data_ptr() + 4, desc, counts, B - 1, dstride,
-                               args.ratio, matches.data_ptr() + cap * 12, nmatches.data_ptr() + 4, cap)
+    def step(serialise=False):
+        d = sets[step_no[0] % len(sets)]
+        step_no[0] += 1
+        with torch.cuda.stream(se):
+            if args.pipeline:
+                se.wait_event(d["matched"])       # recorded two steps ago (a no-op before that)
+            ext.extract_batch_device(images, B, W, H, d["kps"], d["desc"], d["counts"], cap)
+            d["described"].record(se)
+        if serialise:
+            torch.cuda.synchronize(dev)
+        with torch.cuda.stream(sm):
+            if args.pipeline:
+                sm.wait_event(d["described"])
+            mat.match_batch_device(d["desc"], d["counts"], halo_desc, halo_cnt, 1, dstride, args.ratio, d["matches"],
+                                   d["nmatches"], cap)
+            mat.match_batch_device(d["desc"].data_ptr() + dstride, d["counts"].data_ptr() + 4, d["desc"], d["counts"], B - 1,
+                                   dstride, args.ratio, d["matches"].data_ptr() + cap * 12, d["nmatches"].data_ptr() + 4, cap)
+            d["matched"].record(sm)
+        if serialise:
+            torch.cuda.synchronize(dev)
+        return d
+
+    # halo frame = the last frame of the (identical) sequence
+    with torch.cuda.stream(se):
+        ext.extract_batch_device(images, B, W, H, sets[0]["kps"], sets[0]["desc"], sets[0]["counts"], cap)
+        halo_desc.copy_(sets[0]["desc"][B - 1])
+        halo_cnt.copy_(sets[0]["counts"][B - 1:B])
+    torch.cuda.synchronize(dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -188,14 +220,17 @@ def main():
     # matcher's kNN-2); every bracket drains the stream twice. The full per-stage table comes from one extra,
     # untimed step afterwards.
     ext.set_profiling(True, stages=["fast_blur"])
-    mat.set_profiling(True, stages=["knn2"])
+    # the matcher is bracketed in the timed region only when it shares the extractor's stream: a bracket blocks the host
+    # until its stream is drained, and the host has to be free to enqueue the next step's extraction beside the matcher
+    mat.set_profiling(not args.pipeline, stages=["knn2"])
     ext.get_profile(reset=True)
     mat.get_profile(reset=True)
 
     barrier()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()
+        last = step()
     barrier()
     dt = time.perf_counter() - t0
     ext.check()
@@ -208,12 +243,12 @@ def main():
     slow_blocks = ext.slow_path_blocks(reset=True)      # band-kernel workgroups that fell back to dense rescoring
     prof_e, prof_frames = ext.get_profile(reset=True)
     prof_m, prof_pairs = mat.get_profile(reset=True)
-    cnt_host = counts.cpu().numpy()
-    nm_host = nmatches.cpu().numpy()
-    # extra untimed step with every stage bracketed -> stage_us_per_frame
+    cnt_host = last["counts"].cpu().numpy()
+    nm_host = last["nmatches"].cpu().numpy()
+    # extra untimed step with every stage bracketed, extractor and matcher one after the other -> stage_us_per_frame
     ext.set_profiling(True)
     mat.set_profiling(True)
-    step()
+    step(serialise=True)
     torch.cuda.synchronize(dev)
     prof_e_all, frames_all = ext.get_profile(reset=True)
     prof_m_all, pairs_all = mat.get_profile(reset=True)
@@ -247,6 +282,16 @@ def main():
         achieved = fb_bytes_per_launch / (fb_ms_per_launch * 1e-3) / 1e9 if fb_ms_per_launch > 0 else 0.0
         traffic_pf, traffic_src = load_traffic(args.chunk)
         ext_ms = sum(all_ms[k] for k in ("resize", "fast_blur", "select", "describe")) * (prof_frames / max(frames_all, 1))
+        pair_ops = 512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))   # 2 * 256 * sum(nq * nt)
+        if stage_ms.get("knn2"):
+            knn_ms, knn_steps, knn_src = stage_ms["knn2"], args.steps, "timed region"
+        else:
+            knn_ms, knn_steps, knn_src = all_ms["knn2"], 1, "extra untimed step (the timed region does not bracket the matcher's stream)"
+        matcher_roofline = {"kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8 + per-lane top-2)", "bound": "mfma",
+                            "achieved": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12, 1) if knn_ms else None,
+                            "peak": 5000.0, "unit": "TOP/s",
+                            "frac": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12 / 5000.0, 4) if knn_ms else None,
+                            "measured_in": knn_src}
         roofline = {
             "bound": "hbm", "kernel": "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level + bilinear resize to the next level, "
                                       "fused; 8 level launches per pass)" if fused_pyramid else
@@ -263,15 +308,10 @@ def main():
                                 "frac": round(b_extract * prof_frames / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_ms else None},
             "stage_us_per_frame": {k: round(1e3 * all_ms[k] / max(frames_all, 1), 3) for k in all_ms},
             "stage_us_per_frame_note": "every stage bracketed, one extra untimed step after the timed region; the timed "
-                                       "region brackets only fast_blur and knn2 (achieved / avg_launch_ms / matcher)",
+                                       "region brackets only fast_blur (achieved / avg_launch_ms), plus knn2 with --no-pipeline",
             # kNN-2 runs on the matrix cores (knn2_mfma.hip): exact int8 inner products of bit-widened descriptors.
             # ops = 2 * 256 * sum(nq * nt) per launch; peak = 2 x the dense bf16 MFMA peak (MI355X_MICROARCH.md, I8 row)
-            "matcher": {"kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8 + per-lane top-2)", "bound": "mfma",
-                        "achieved": round(512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))
-                                          * args.steps / (stage_ms["knn2"] * 1e-3) / 1e12, 1) if stage_ms["knn2"] else None,
-                        "peak": 5000.0, "unit": "TOP/s",
-                        "frac": round(512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))
-                                      * args.steps / (stage_ms["knn2"] * 1e-3) / 1e12 / 5000.0, 4) if stage_ms["knn2"] else None},
+            "matcher": matcher_roofline,
         }
         out = {
             "metric": "frames/s ORB extract+BF-match, 640x480 @2000 kp" if (W, H, NF) == (640, 480, 2000)
@@ -284,6 +324,8 @@ def main():
                                    "resident in HBM" % (args.pairs, W, H, B, NF),
                        "frames_per_gpu_per_step": B, "chunk_frames": args.chunk, "ratio": args.ratio,
                        "parallelism": "frames sharded by contiguous range, %d rank(s), no collective" % n_gpus,
+                       "streams": ("extractor and matcher on two streams, double-buffered outputs: the matcher of step s "
+                                   "runs beside the extractor of step s+1") if args.pipeline else "one stream",
                        "mean_keypoints_per_frame": round(float(cnt_host.mean()), 2),
                        "mean_matches_per_frame": round(float(nm_host.mean()), 2),
                        "slow_path_blocks": int(slow_blocks)},
