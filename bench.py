@@ -291,7 +291,12 @@ def main():
                             "achieved": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12, 1) if knn_ms else None,
                             "peak": 5000.0, "unit": "TOP/s",
                             "frac": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12 / 5000.0, 4) if knn_ms else None,
-                            "measured_in": knn_src}
+                            "measured_in": knn_src,
+                            # the matcher's HBM share is tiny (B_match = 32 (Nq + Nt) + 16 Nq per pair) and its
+                            # work in the units of the popcount formulation is 8 dword xor+popcounts per descriptor pair
+                            "hbm_frac": round((32.0 * float(cnt_host[1:].sum() + cnt_host[:-1].sum()) + 16.0 * float(cnt_host[1:].sum()))
+                                              * knn_steps / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if knn_ms else None,
+                            "popcount_dword_equivalents_per_s": round(pair_ops / 64.0 * knn_steps / (knn_ms * 1e-3), 1) if knn_ms else None}
         roofline = {
             "bound": "hbm", "kernel": "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level + bilinear resize to the next level, "
                                       "fused; 8 level launches per pass)" if fused_pyramid else
