@@ -488,3 +488,65 @@ def test_profiling_stage_masks(aria, torch_cuda):
     finally:
         e.close()
         m.close()
+
+
+def test_borrowed_stream_orders_extractor_and_matcher(aria, torch_cuda):
+    """Two handles that borrow ONE real stream run in order without any host sync in between (bench.py's serial mode);
+    with two streams the same holds once the matcher's stream waits for an event recorded after the extraction
+    (bench.py's pipelined mode). Both must equal the host-synchronised result. (torch's default stream has handle 0,
+    which means "no stream": handles given 0 create their own, unordered streams.)"""
+    torch = torch_cuda
+    W, H, NF, B = 640, 480, 1000, 6
+    seq = aria.synth_sequence(91, 3, W, H)[:B]
+    dev = torch.device("cuda", 0)
+    images = torch.from_numpy(seq).to(dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    assert s1.cuda_stream != 0 and s2.cuda_stream != 0
+    torch.cuda.synchronize()
+
+    def run(mode):
+        e = aria.OrbHipExtractor(max_features=NF, stream=s1.cuda_stream, max_width=W, max_height=H, max_batch=B)
+        m = aria.HipMatcher(stream=(s1 if mode != "two_streams" else s2).cuda_stream)
+        try:
+            assert e.stream == s1.cuda_stream
+            cap = e.kp_capacity()
+            kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+            desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+            counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+            matches = torch.zeros((B, cap, 12), dtype=torch.uint8, device=dev)
+            nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(3):                      # repeated, so a too-early matcher would see the zeroed buffers below
+                with torch.cuda.stream(s1):
+                    desc.zero_()
+                    counts.zero_()
+                    e.extract_batch_device(images, B, W, H, kps, desc, counts, cap)
+                    ev = torch.cuda.Event()
+                    ev.record(s1)
+                if mode == "host_sync":
+                    e.check()
+                ms = s1 if mode != "two_streams" else s2
+                with torch.cuda.stream(ms):
+                    if mode == "two_streams":
+                        s2.wait_event(ev)
+                    m.match_batch_device(desc.data_ptr() + cap * 32, counts.data_ptr() + 4, desc, counts, B - 1, cap * 32,
+                                         0.75, matches, nm, cap)
+                    done = torch.cuda.Event()
+                    done.record(ms)
+                if mode == "two_streams":
+                    s1.wait_event(done)             # the next round zeroes the buffers the matcher is reading
+            torch.cuda.synchronize()
+            e.check()
+            m.sync()
+            n = nm.cpu().numpy().copy()
+            mm = matches.cpu().numpy().copy()
+            return n, [mm[p, :n[p]].tobytes() for p in range(B - 1)]
+        finally:
+            e.close()
+            m.close()
+
+    ref = run("host_sync")
+    assert ref[0][:B - 1].min() > 0
+    for mode in ("one_stream", "two_streams"):
+        got = run(mode)
+        assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], mode
