@@ -14,7 +14,15 @@ char* last_hip_error_buf();
 
 inline int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     std::snprintf(last_hip_error_buf(), 256, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
-    return e == hipErrorOutOfMemory ? ARIA_E_OOM : ARIA_E_NO_DEVICE;
+    switch (e) {
+        case hipErrorOutOfMemory: return ARIA_E_OOM;
+        case hipErrorNoDevice: case hipErrorInvalidDevice: case hipErrorInsufficientDriver: case hipErrorNotInitialized:
+            return ARIA_E_NO_DEVICE;
+        case hipErrorLaunchFailure: case hipErrorIllegalAddress: case hipErrorLaunchTimeOut: case hipErrorAssert:
+        case hipErrorLaunchOutOfResources: case hipErrorSharedObjectInitFailed:
+            return ARIA_E_KERNEL;
+        default: return ARIA_E_HIP;
+    }
 }
 
 #define ARIA_HIP(call)                                                          \

@@ -35,15 +35,14 @@ constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a st
 // Workgroup geometry for a level of width w: NB vertically stacked strips of R rows share one staged block of
 // NB*R + 8 rows; thread = (strip, 4-px column). NB is chosen so the waves are full even on narrow levels.
 struct BandCfg { int nb, lpr, nthr, qcap; size_t lds; };
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static BandCfg band_cfg(const Plan& P, int w, int level) {
     // Occupancy is what this kernel is short of (2-3 waves per SIMD), and LDS is what limits it, so the LDS budget per
     // workgroup is small and the survivor queue is sized by how corner-dense a level is expected to be: the compass
     // test passes ~3 % of level-0 pixels but 25-30 % at level 7 on the benchmark frames (coarse levels pack more
     // structure per pixel). A full queue is not an error: that block takes the slow rescoring path and is counted
     // (aria_orb_slow_path_blocks); the host raises band_qpct0 when it sees such blocks.
-    static const int env_budget = env_int("ARIA_BAND_BUDGET_KB", 0), env_q0 = env_int("ARIA_BAND_QPCT0", -1),
-                     env_qs = env_int("ARIA_BAND_QPCT_STEP", -1);
+    const EnvConfig& E = env_config();
+    const int env_budget = E.band_budget_kb, env_q0 = E.band_qpct0, env_qs = E.band_qstep;
     const int budget_kb = env_budget > 0 ? env_budget : P.band_budget_kb;
     const int q0 = env_q0 >= 0 ? env_q0 : P.band_qpct0, qstep = env_qs >= 0 ? env_qs : P.band_qstep;
     const size_t budget = (size_t)budget_kb * 1024;
@@ -511,41 +510,40 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
 #undef STAMP
 }
 
-void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
-                           Profiler* prof, bool fuse_resize) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        attr_set = true;
-    }
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("ARIA_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing experiments only
+int band_set_attributes() {
+    const int lds_max = 160 * 1024 - 64;
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_band<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    return ARIA_OK;
+}
+
+int band_init_ctx(LaunchCtx& ctx) {
+    const EnvConfig& E = env_config();
     // The 8 levels are independent; ARIA_LEVEL_STREAMS=1 forks them onto side streams and joins back on the caller's
-    // stream (useful for small batches where a level's grid does not fill the chip).
-    static hipStream_t side[kLevels] = {};
-    static hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {};
-    static int use_side = -1;
-    if (use_side < 0) {
-        const char* e = getenv("ARIA_LEVEL_STREAMS");
-        use_side = (e && e[0] == '1') ? 1 : 0;   // measured: no gain over back-to-back launches at chunk >= 256; off by default
-        if (use_side) {
-            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-            for (int l = 1; l < kLevels; l++) {
-                hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking);
-                hipEventCreateWithFlags(&ev_join[l], hipEventDisableTiming);
-            }
+    // stream (measured: no gain over back-to-back launches at chunk >= 256; off by default).
+    if (E.level_streams) {
+        ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_fork, hipEventDisableTiming));
+        for (int l = 1; l < kLevels; l++) {
+            ARIA_HIP(hipStreamCreateWithFlags(&ctx.side[l], hipStreamNonBlocking));
+            ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_join[l], hipEventDisableTiming));
         }
     }
-    static unsigned long long* d_stamps = nullptr;
-    static int stamp_level = -2;
-    if (stamp_level == -2) {
-        const char* e = getenv("ARIA_STAMPS");
-        stamp_level = e ? atoi(e) : -1;
-        if (stamp_level >= 0) hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * 65536);
-    }
+    if (E.stamp_level >= 0) ARIA_HIP(hipMalloc(&ctx.d_band_stamps, sizeof(unsigned long long) * 8 * 65536));
+    return ARIA_OK;
+}
+
+void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                           Profiler* prof, bool fuse_resize, LaunchCtx& ctx) {
+    const EnvConfig& E = env_config();
+    const int ablate = E.ablate;
+    const bool use_side = E.level_streams && ctx.ev_fork != nullptr;
+    hipStream_t* side = ctx.side;
+    hipEvent_t ev_fork = ctx.ev_fork;
+    hipEvent_t* ev_join = ctx.ev_join;
+    unsigned long long* d_stamps = ctx.d_band_stamps;
+    const int stamp_level = d_stamps ? E.stamp_level : -1;
     if (use_side) hipEventRecord(ev_fork, st);
     for (int l = 0; l < kLevels; l++) {
         const LevelGeom& g = P.lv[l];

@@ -51,6 +51,7 @@ struct aria_orb_s {
     FrameSrc last_src{};
     bool have_last = false;
     Profiler prof;
+    LaunchCtx ctx;          // per-handle launch state (function attributes of this device, side streams, stamp buffers)
 };
 
 namespace {
@@ -146,7 +147,7 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1, (pitch % 16 == 0 && ((int64_t)pitch * height) % 16 == 0) ? 1 : 0};
     h->last_src = S;
     h->have_last = true;
-    launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof);
+    launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof, h->ctx);
     ARIA_HIP(hipGetLastError());
     ARIA_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
     ARIA_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, 32 * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
@@ -181,7 +182,9 @@ const char* aria_status_string(int s) {
     switch (s) {
         case ARIA_OK: return "ok";
         case ARIA_E_INVALID: return "invalid argument";
-        case ARIA_E_NO_DEVICE: return "no usable HIP device or HIP runtime error";
+        case ARIA_E_NO_DEVICE: return "no usable HIP device";
+        case ARIA_E_HIP: return "HIP runtime call failed";
+        case ARIA_E_KERNEL: return "kernel launch failed or faulted";
         case ARIA_E_OOM: return "out of memory";
         case ARIA_E_TOO_LARGE: return "image larger than the handle was created for";
         case ARIA_E_OUTPUT_TOO_SMALL: return "output capacity too small";
@@ -238,7 +241,8 @@ int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
         if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
         h->owns_stream = true;
     }
-    int rc = alloc_scratch(h);
+    int rc = h->ctx.init(c->device);
+    if (rc == ARIA_OK) rc = alloc_scratch(h);
     if (rc != ARIA_OK) { aria_orb_destroy(h); return rc; }
     *out = h;
     return ARIA_OK;
@@ -249,6 +253,7 @@ void aria_orb_destroy(aria_orb_t h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     h->prof.release();
+    h->ctx.release();
     free_scratch(h);
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -321,7 +326,7 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
         FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4, aligned16};
         if (f0 == 0) { h->last_src = S; h->have_last = true; }
         launch_extract_chunk(h->plan, S, h->D, nf, d_keypoints + (int64_t)f0 * kp_cap,
-                             d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream, &h->prof);
+                             d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream, &h->prof, h->ctx);
     }
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;

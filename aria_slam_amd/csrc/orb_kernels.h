@@ -59,6 +59,35 @@ struct Profiler {
     void release();
 };
 
+// Per-handle launch state. Everything a launcher needs besides the plan and the scratch lives here, so two handles
+// (two host threads, two devices, two streams) never share mutable state: the kernels' function attributes are set
+// for the handle's device when the handle is created, and the optional side streams / diagnostic stamp buffers
+// belong to the handle. The environment is read once per process into an immutable EnvConfig.
+struct EnvConfig {
+    int ablate;            // ARIA_ABLATE (timing experiments: results invalid), honoured by diagnostic builds only
+    int level_streams;     // ARIA_LEVEL_STREAMS=1: one side stream per level
+    int stamp_level;       // ARIA_STAMPS=<level>: phase stamps of the band kernel, -1 = off
+    int sel_stamps;        // ARIA_SEL_STAMPS=1
+    int desc_stamps;       // ARIA_DESC_STAMPS=1
+    int fast_blur_impl;    // 1 = band kernel (default), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
+    int fuse_resize;       // pyramid step fused into the FAST/blur launches (default 1)
+    int pyr_impl;          // 1 = fused in-LDS pyramid (ARIA_PYRAMID_IMPL=fused)
+    int rs_impl;           // stand-alone resize pass: 2 dot2 LDS bands, 1 shift/mad LDS bands, 0 direct gathers
+    int band_budget_kb, band_qpct0, band_qstep;   // ARIA_BAND_*: <0 / 0 = plan defaults
+};
+const EnvConfig& env_config();
+
+struct LaunchCtx {
+    int device = -1;
+    hipStream_t side[kLevels] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {};
+    unsigned long long* d_band_stamps = nullptr;
+    unsigned long long* d_sel_stamps = nullptr;
+    unsigned long long* d_desc_stamps = nullptr;
+    int init(int device);      // current device = `device`; returns an aria_status
+    void release();
+};
+
 // Launch `kernel`; counted into the open stage when profiling is on.
 #define ARIA_LAUNCH(prof, kernel, grid, block, lds, st, ...)                       \
     do {                                                                           \
@@ -70,11 +99,12 @@ struct Profiler {
 // fuse_resize: every level's launch also writes the raw rows of the next level (the caller then skips the resize pass;
 // the launches must stay in level order on one stream)
 void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
-                           Profiler* prof, bool fuse_resize);
-int fast_blur_impl();   // 1 = band (default), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
+                           Profiler* prof, bool fuse_resize, LaunchCtx& ctx);
+int band_set_attributes();          // hipFuncSetAttribute of the band kernels on the current device (aria_status)
+int band_init_ctx(LaunchCtx& ctx);  // side streams / stamp buffer when the environment asks for them
 
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
-                          Profiler* prof);
+                          Profiler* prof, LaunchCtx& ctx);
 
 }  // namespace aria

@@ -1223,19 +1223,37 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
-int fast_blur_impl() {
-    static int impl = -1;
-    if (impl < 0) {
-        const char* e = getenv("ARIA_FAST_BLUR_IMPL");
-        impl = (e && e[0] == 't') ? 0 : 1;
-    }
-    return impl;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static bool env_is(const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; }
+
+// The environment is read once per process (thread-safe static initialisation) and never written again.
+const EnvConfig& env_config() {
+    static const EnvConfig cfg = [] {
+        EnvConfig c{};
+        c.ablate = env_int("ARIA_ABLATE", 0);
+        c.level_streams = env_is("ARIA_LEVEL_STREAMS", '1') ? 1 : 0;
+        c.stamp_level = env_int("ARIA_STAMPS", -1);
+        c.sel_stamps = env_is("ARIA_SEL_STAMPS", '1') ? 1 : 0;
+        c.desc_stamps = env_is("ARIA_DESC_STAMPS", '1') ? 1 : 0;
+        c.fast_blur_impl = env_is("ARIA_FAST_BLUR_IMPL", 't') ? 0 : 1;
+        c.pyr_impl = env_is("ARIA_PYRAMID_IMPL", 'f') ? 1 : 0;
+        c.rs_impl = env_is("ARIA_RESIZE_IMPL", 'd') ? 0 : env_is("ARIA_RESIZE_IMPL", 'l') ? 1 : 2;
+        // A separate resize pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL, ARIA_PYRAMID_IMPL) or when
+        // the band kernel is not the one in use (tile kernel, per-level side streams).
+        c.fuse_resize = (c.fast_blur_impl == 1 && !env_is("ARIA_RESIZE_FUSE", '0') && !getenv("ARIA_RESIZE_IMPL") &&
+                         !getenv("ARIA_PYRAMID_IMPL") && !c.level_streams) ? 1 : 0;
+        c.band_budget_kb = env_int("ARIA_BAND_BUDGET_KB", 0);
+        c.band_qpct0 = env_int("ARIA_BAND_QPCT0", -1);
+        c.band_qstep = env_int("ARIA_BAND_QPCT_STEP", -1);
+        return c;
+    }();
+    return cfg;
 }
 
 hipEvent_t Profiler::get() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 void Profiler::begin(int stage, hipStream_t st) {
@@ -1268,16 +1286,39 @@ void Profiler::release() {
     pool.clear();
 }
 
+int LaunchCtx::init(int dev) {
+    device = dev;
+    const EnvConfig& E = env_config();
+    // kernels that may need more than the default 64 KB of dynamic LDS: the attribute belongs to (function, device),
+    // so every handle sets it for its own device
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(unsigned long long) * kSortCapMax)));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    int rc = band_set_attributes();
+    if (rc != ARIA_OK) return rc;
+    rc = band_init_ctx(*this);
+    if (rc != ARIA_OK) return rc;
+    if (E.sel_stamps) ARIA_HIP(hipMalloc(&d_sel_stamps, sizeof(unsigned long long) * 8 * kLevels * 4096));
+    if (E.desc_stamps) ARIA_HIP(hipMalloc(&d_desc_stamps, sizeof(unsigned long long) * 8 * (1u << 22)));
+    return ARIA_OK;
+}
+
+void LaunchCtx::release() {
+    for (int l = 0; l < kLevels; l++) {
+        if (side[l]) hipStreamDestroy(side[l]);
+        if (ev_join[l]) hipEventDestroy(ev_join[l]);
+        side[l] = nullptr; ev_join[l] = nullptr;
+    }
+    if (ev_fork) hipEventDestroy(ev_fork);
+    ev_fork = nullptr;
+    hipFree(d_band_stamps); hipFree(d_sel_stamps); hipFree(d_desc_stamps);
+    d_band_stamps = d_sel_stamps = d_desc_stamps = nullptr;
+}
+
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
-                          Profiler* prof) {
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // kernels that may need more than the default 64 KB of dynamic LDS
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(unsigned long long) * kSortCapMax));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        lds_attr_set = true;
-    }
+                          Profiler* prof, LaunchCtx& ctx) {
+    const EnvConfig& E = env_config();
     if (prof && prof->enabled) prof->frames += n_frames;
     hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
 
@@ -1285,25 +1326,18 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     // Default: no pass of its own -- the FAST/blur launch of level l writes the raw rows of level l+1 from the rows it
     // has staged (fast_blur_band.hip). A separate pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL,
     // ARIA_PYRAMID_IMPL) or when the band kernel is not the one in use (tile kernel, per-level side streams).
-    static const bool fuse_resize = [] {
-        const char* f = getenv("ARIA_RESIZE_FUSE");
-        const char* ls = getenv("ARIA_LEVEL_STREAMS");
-        return fast_blur_impl() == 1 && !(f && f[0] == '0') && !getenv("ARIA_RESIZE_IMPL") && !getenv("ARIA_PYRAMID_IMPL") &&
-               !(ls && ls[0] == '1');
-    }();
+    const bool fuse_resize = E.fuse_resize != 0;
     if (!fuse_resize) {
     if (prof) prof->begin(STAGE_RESIZE, st);
-    static int pyr_impl = -1;   // 0 = one resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
-                                // measured slower at 640x480: the top-down halo makes small bands recompute too much)
-    if (pyr_impl < 0) { const char* e = getenv("ARIA_PYRAMID_IMPL"); pyr_impl = (e && e[0] == 'f') ? 1 : 0; }
+    const int pyr_impl = E.pyr_impl;   // 0 = one resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
+                                       // measured slower at 640x480: the top-down halo makes small bands recompute too much)
     if (pyr_impl == 1 && P.pyr_lds_bytes <= 150 * 1024) {
         ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S,
                     D.raw, D.tab, D.pyr_bands);
     } else {
         // 2 = LDS-staged bands with dot2 arithmetic (default), 1 = LDS-staged bands with shift/mad arithmetic
         // (ARIA_RESIZE_IMPL=lds), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)
-        static int rs_impl = -1;
-        if (rs_impl < 0) { const char* e = getenv("ARIA_RESIZE_IMPL"); rs_impl = (e && e[0] == 'd') ? 0 : (e && e[0] == 'l') ? 1 : 2; }
+        const int rs_impl = E.rs_impl;
         for (int l = 1; l < kLevels; l++) {
             if (rs_impl >= 1) {
                 const int lp = (P.lv[l - 1].w + 15) / 16 * 16 + 16;
@@ -1330,8 +1364,8 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
 
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
-    if (fast_blur_impl() == 1) {
-        launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize);
+    if (E.fast_blur_impl == 1) {
+        launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     } else {
         ARIA_LAUNCH(prof, k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur,
                     D.cand, D.cand_cnt, D.err);
@@ -1341,10 +1375,8 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
 
     // ---- a6.3-a6.5 selection ----
     if (prof) prof->begin(STAGE_SELECT, st);
-    static unsigned long long* d_sstamps = nullptr;     // diagnostic: ARIA_SEL_STAMPS=1 prints mean phase lengths per level
-    static const int want_sstamps = [] { const char* e = getenv("ARIA_SEL_STAMPS"); return (e && e[0] == '1') ? 1 : 0; }();
-    if (want_sstamps && !d_sstamps) hipMalloc(&d_sstamps, sizeof(unsigned long long) * 8 * kLevels * 4096);
-    unsigned long long* sstp = (want_sstamps && n_frames <= 4096) ? d_sstamps : nullptr;
+    // diagnostic: ARIA_SEL_STAMPS=1 prints mean phase lengths per level
+    unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;
     if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
     ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
                 st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp);
@@ -1372,12 +1404,9 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     {
         const int bpf = (P.sel_frame_entries + kDescKp - 1) / kDescKp;
         const int frames8 = (n_frames + 7) / 8 * 8;
-        static unsigned long long* d_stamps = nullptr;     // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
-        static int want_stamps = -1;
-        if (want_stamps < 0) { const char* e = getenv("ARIA_DESC_STAMPS"); want_stamps = (e && e[0] == '1') ? 1 : 0; }
         const size_t nwaves = (size_t)bpf * frames8 * kDescWaves;
-        if (want_stamps && !d_stamps && nwaves <= (1u << 22)) hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * (1u << 22));
-        unsigned long long* stp = (want_stamps && nwaves <= (1u << 22)) ? d_stamps : nullptr;
+        // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
+        unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
         ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
                     D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp);

@@ -54,19 +54,26 @@ class KeyframeDB:
         self.ids[self.n] = int(kf_id)
         self.n += 1
 
-    def all_gather(self, group=None):
+    def all_gather(self, group=None, via_host=False):
         """One all-gather per tensor of the padded slots (uniform message sizes). Returns a KeyframeDB holding
-        world*k_cap slots; empty slots keep count 0 and are skipped by the scorer."""
+        world*k_cap slots; empty slots keep count 0 and are skipped by the scorer. With backend "nccl" (RCCL) the
+        device tensors are gathered in place over xGMI; via_host=True stages through host memory for a CPU-only
+        backend (gloo rehearsal of a device-resident DB)."""
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(group)
+        dev = self.desc.device
         g = KeyframeDB.__new__(KeyframeDB)
         g.k_cap, g.rows = self.k_cap * world, self.rows
-        g.desc = torch.empty((g.k_cap, self.rows, 32), dtype=torch.uint8, device=self.desc.device)
-        g.counts = torch.empty((g.k_cap,), dtype=torch.int32, device=self.desc.device)
-        g.ids = torch.empty((g.k_cap,), dtype=torch.int64, device=self.desc.device)
+        gdev = torch.device("cpu") if via_host else dev
+        g.desc = torch.empty((g.k_cap, self.rows, 32), dtype=torch.uint8, device=gdev)
+        g.counts = torch.empty((g.k_cap,), dtype=torch.int32, device=gdev)
+        g.ids = torch.empty((g.k_cap,), dtype=torch.int64, device=gdev)
         for dst, src in ((g.desc, self.desc), (g.counts, self.counts), (g.ids, self.ids)):
-            dist.all_gather_into_tensor(dst.view(-1), src.contiguous().view(-1), group=group)
+            src = src.contiguous().view(-1)
+            dist.all_gather_into_tensor(dst.view(-1), src.cpu() if via_host else src, group=group)
+        if via_host:
+            g.desc, g.counts, g.ids = g.desc.to(dev), g.counts.to(dev), g.ids.to(dev)
         g.n = g.k_cap
         return g
 

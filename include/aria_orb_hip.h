@@ -37,14 +37,16 @@ extern "C" {
 typedef enum {
     ARIA_OK = 0,
     ARIA_E_INVALID = -1,          /* bad argument (null pointer, size out of range, bad struct_size)        */
-    ARIA_E_NO_DEVICE = -2,        /* no usable HIP device / HIP runtime error (see aria_last_hip_error)     */
+    ARIA_E_NO_DEVICE = -2,        /* no usable HIP device (none present, bad ordinal, driver/runtime not initialised) */
     ARIA_E_OOM = -3,              /* device or host allocation failed                                       */
     ARIA_E_TOO_LARGE = -4,        /* image larger than the handle was created for                           */
     ARIA_E_OUTPUT_TOO_SMALL = -5, /* caller's keypoint/match capacity is smaller than the result            */
     ARIA_E_OVERFLOW = -6,         /* an internal candidate/sort buffer overflowed (pathological image);
                                      results are NOT valid. Raise cand_cap_scale and retry.                 */
     ARIA_E_BUSY = -7,             /* extract_async called while another async extract is pending            */
-    ARIA_E_NOT_PENDING = -8       /* sync called with nothing pending (treated as a no-op by the adapter)   */
+    ARIA_E_NOT_PENDING = -8,      /* sync called with nothing pending (treated as a no-op by the adapter)   */
+    ARIA_E_HIP = -9,              /* a HIP runtime call failed (bad pointer, bad stream, ...): aria_last_hip_error() */
+    ARIA_E_KERNEL = -10           /* a kernel launch failed or faulted on the device: aria_last_hip_error()  */
 } aria_status;
 
 /* == aria::core::KeyPoint (include/core/Types.hpp:9-15), 24 bytes */

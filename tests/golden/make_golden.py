@@ -6,7 +6,11 @@ goldens are produced by THIS repo's CPU oracle on seeded synthetic frames. They 
 (b) the oracle against accidental change, and (c) give the GPU tests a fixture that does not need the oracle
 at run time. They do NOT pin the oracle against real OpenCV (parity unpinned, see oracle/orb_oracle.h).
 
-Usage: python tests/golden/make_golden.py   (rewrites golden.json and golden_seed1_640x480.npz)
+Usage: python tests/golden/make_golden.py            (rewrites golden.json and golden_seed1_640x480.npz)
+       python tests/golden/make_golden.py --bench    (rewrites bench_prefix.json: oracle digests of the first 256
+                                                      frames of bench.py's default sequence, seeds 1..128, and of
+                                                      their (frame, previous frame) matches -- what bench.py's
+                                                      `verified` compares the timed batch path with)
 """
 import hashlib
 import json
@@ -52,5 +56,44 @@ def main():
     print("wrote", os.path.join(HERE, "golden.json"))
 
 
+def _bench_pair(args):
+    seed, w, h, nf = args
+    a, b = A.synth_frame_pair(seed, w, h)
+    p = O.default_params(nf)
+    ka, da = O.orb_extract(a, p)
+    kb, db = O.orb_extract(b, p)
+    return seed, (ka, da), (kb, db)
+
+
+def bench_prefix(n_frames=256, w=640, h=480, nf=2000, ratio=0.75):
+    """Digests exactly as bench.py's frame_digest / match_digest compute them (first 16 hex chars kept)."""
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import bench as B
+    with mp.get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+        res = sorted(pool.map(_bench_pair, [(1 + s, w, h, nf) for s in range(n_frames // 2)]))
+    frames = []
+    for _, fa, fb in res:
+        frames += [fa, fb]
+    fd = [B.frame_digest(len(k), k, d)[:16] for k, d in frames]
+    md = [""]
+    for f in range(1, n_frames):
+        m = O.match_ratio(frames[f][1], frames[f - 1][1], ratio)
+        md.append(B.match_digest(len(m), m)[:16])
+    path = os.path.join(HERE, "bench_prefix.json")
+    g = json.load(open(path)) if os.path.exists(path) else {}
+    key = "%dx%d_n%d" % (w, h, nf)
+    full = g.get(key, {}).get("full", {})
+    g[key] = {"ratio": ratio, "seed0": 1, "frames": n_frames, "frame": fd, "match": md, "full": full,
+              "made_by": "tests/golden/make_golden.py --bench (oracle/orb_oracle.cpp); 'full' = checksum of checksums "
+                         "of the whole default sequence as printed by bench.py on the GPU (HIP path whose prefix "
+                         "equals these oracle digests)"}
+    json.dump(g, open(path, "w"), indent=0, sort_keys=True)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
-    main()
+    if "--bench" in sys.argv:
+        bench_prefix()
+    else:
+        main()

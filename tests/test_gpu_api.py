@@ -550,3 +550,45 @@ def test_borrowed_stream_orders_extractor_and_matcher(aria, torch_cuda):
     for mode in ("one_stream", "two_streams"):
         got = run(mode)
         assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], mode
+
+
+# ---- handles are independent: no process-wide launch state ---------------------------------------------------
+def test_two_handles_from_two_host_threads(aria, oracle):
+    """include/aria_orb_hip.h: independent handles on different streams may run concurrently (the reference's adapters are
+    one-instance-per-thread objects, include/adapters/gpu/OrbCudaExtractor.hpp:38-50). Two host threads each create
+    their own extractor + matcher, work at the same time on different sizes, and both equal the oracle."""
+    import threading
+    jobs = [(11, 640, 480, 2000), (12, 752, 480, 1000)]
+    out, errs = {}, []
+
+    def work(i):
+        seed, w, h, nf = jobs[i]
+        try:
+            a, b = aria.synth_frame_pair(seed, w, h)
+            e = aria.OrbHipExtractor(max_features=nf, max_width=w, max_height=h)
+            m = aria.HipMatcher(max_query=nf + 1024, max_train=nf + 1024)
+            try:
+                res = []
+                for _ in range(6):                       # several rounds so the two threads really overlap
+                    fa, fb = e.extract(a), e.extract(b)
+                    res.append((fa, fb, m.match(fb, fa, None, 0.75)))
+                out[i] = res
+            finally:
+                e.close()
+                m.close()
+        except Exception as ex:                          # surfaced in the main thread
+            errs.append((i, ex))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i, (seed, w, h, nf) in enumerate(jobs):
+        a, b = aria.synth_frame_pair(seed, w, h)
+        p = oracle.default_params(nf)
+        (ka, da), (kb, db) = oracle.orb_extract(a, p), oracle.orb_extract(b, p)
+        want = oracle.match_ratio(db, da, 0.75)
+        for fa, fb, got in out[i]:
+            assert fa["keypoints"].tobytes() == ka.tobytes() and np.array_equal(fa["descriptors"], da)
+            assert fb["keypoints"].tobytes() == kb.tobytes() and np.array_equal(fb["descriptors"], db)
+            assert got.tobytes() == want.tobytes()
