@@ -530,7 +530,7 @@ int band_init_ctx(LaunchCtx& ctx) {
             ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_join[l], hipEventDisableTiming));
         }
     }
-    if (E.stamp_level >= 0) ARIA_HIP(hipMalloc(&ctx.d_band_stamps, sizeof(unsigned long long) * 8 * 65536));
+    if (E.stamp_level >= 0) ARIA_HIP(hipMalloc(&ctx.d_band_stamps, sizeof(unsigned long long) * 16 * 32768));
     return ARIA_OK;
 }
 

@@ -69,7 +69,9 @@ struct EnvConfig {
     int stamp_level;       // ARIA_STAMPS=<level>: phase stamps of the band kernel, -1 = off
     int sel_stamps;        // ARIA_SEL_STAMPS=1
     int desc_stamps;       // ARIA_DESC_STAMPS=1
-    int fast_blur_impl;    // 1 = band kernel (default), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
+    int fast_blur_impl;    // 2 = band kernel, all VALU (fast_blur_band.hip, default), 1 = band kernel with the blur on the
+                           // matrix cores (band_mfma.hip, ARIA_FAST_BLUR_IMPL=mfma: same bits, 23 % fewer VALU instructions,
+                           // same time -- DESIGN.md section 4), 0 = 64x32 LDS tiles (ARIA_FAST_BLUR_IMPL=tile)
     int fuse_resize;       // pyramid step fused into the FAST/blur launches (default 1)
     int pyr_impl;          // 1 = fused in-LDS pyramid (ARIA_PYRAMID_IMPL=fused)
     int rs_impl;           // stand-alone resize pass: 2 dot2 LDS bands, 1 shift/mad LDS bands, 0 direct gathers
@@ -100,6 +102,10 @@ struct LaunchCtx {
 // the launches must stay in level order on one stream)
 void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
                            Profiler* prof, bool fuse_resize, LaunchCtx& ctx);
+// round-2 band kernel (band_mfma.hip): same contract as launch_fast_blur_band
+void launch_band2(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof,
+                  bool fuse_resize, LaunchCtx& ctx);
+int band2_set_attributes();
 int band_set_attributes();          // hipFuncSetAttribute of the band kernels on the current device (aria_status)
 int band_init_ctx(LaunchCtx& ctx);  // side streams / stamp buffer when the environment asks for them
 

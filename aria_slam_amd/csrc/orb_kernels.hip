@@ -1235,12 +1235,12 @@ const EnvConfig& env_config() {
         c.stamp_level = env_int("ARIA_STAMPS", -1);
         c.sel_stamps = env_is("ARIA_SEL_STAMPS", '1') ? 1 : 0;
         c.desc_stamps = env_is("ARIA_DESC_STAMPS", '1') ? 1 : 0;
-        c.fast_blur_impl = env_is("ARIA_FAST_BLUR_IMPL", 't') ? 0 : 1;
+        c.fast_blur_impl = env_is("ARIA_FAST_BLUR_IMPL", 't') ? 0 : env_is("ARIA_FAST_BLUR_IMPL", 'm') ? 1 : 2;
         c.pyr_impl = env_is("ARIA_PYRAMID_IMPL", 'f') ? 1 : 0;
         c.rs_impl = env_is("ARIA_RESIZE_IMPL", 'd') ? 0 : env_is("ARIA_RESIZE_IMPL", 'l') ? 1 : 2;
         // A separate resize pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL, ARIA_PYRAMID_IMPL) or when
         // the band kernel is not the one in use (tile kernel, per-level side streams).
-        c.fuse_resize = (c.fast_blur_impl == 1 && !env_is("ARIA_RESIZE_FUSE", '0') && !getenv("ARIA_RESIZE_IMPL") &&
+        c.fuse_resize = (c.fast_blur_impl != 0 && !env_is("ARIA_RESIZE_FUSE", '0') && !getenv("ARIA_RESIZE_IMPL") &&
                          !getenv("ARIA_PYRAMID_IMPL") && !c.level_streams) ? 1 : 0;
         c.band_budget_kb = env_int("ARIA_BAND_BUDGET_KB", 0);
         c.band_qpct0 = env_int("ARIA_BAND_QPCT0", -1);
@@ -1295,6 +1295,8 @@ int LaunchCtx::init(int dev) {
                                  (int)(sizeof(unsigned long long) * kSortCapMax)));
     ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     int rc = band_set_attributes();
+    if (rc != ARIA_OK) return rc;
+    rc = band2_set_attributes();
     if (rc != ARIA_OK) return rc;
     rc = band_init_ctx(*this);
     if (rc != ARIA_OK) return rc;
@@ -1364,7 +1366,9 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
 
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
-    if (E.fast_blur_impl == 1) {
+    if (E.fast_blur_impl == 1 && !E.level_streams) {
+        launch_band2(P, S, D, n_frames, st, prof, fuse_resize, ctx);
+    } else if (E.fast_blur_impl != 0) {
         launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     } else {
         ARIA_LAUNCH(prof, k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur,

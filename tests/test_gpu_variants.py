@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     {},
     {"ARIA_FAST_BLUR_IMPL": "tile"},
+    {"ARIA_FAST_BLUR_IMPL": "mfma"},                               # band kernel with the 7x7 blur on the matrix cores (band_mfma.hip)
     {"ARIA_RESIZE_FUSE": "0"},                                     # separate resize pass (dot2 LDS kernel)
     {"ARIA_RESIZE_IMPL": "direct"},
     {"ARIA_RESIZE_IMPL": "lds"},                                   # LDS-staged resize with shift/mad arithmetic
