@@ -21,7 +21,7 @@ ARIA_E_NOT_PENDING = -8
 EXPORTS = [
     "aria_status_string", "aria_abi_version", "aria_last_hip_error",
     "aria_orb_default_config", "aria_orb_create", "aria_orb_destroy", "aria_orb_set_max_features",
-    "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_extract", "aria_orb_extract_async",
+    "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_rows_needed", "aria_orb_fetch_last", "aria_orb_extract", "aria_orb_extract_async",
     "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream", "aria_orb_slow_path_blocks",
     "aria_orb_set_profiling", "aria_orb_get_profile", "aria_matcher_set_profiling", "aria_matcher_get_profile",
     "aria_orb_level_info", "aria_orb_resize_table", "aria_orb_pyramid_bands", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
@@ -125,6 +125,8 @@ def load_library():
     L.aria_orb_set_max_features.argtypes = [C.c_void_p, C.c_int]
     L.aria_orb_get_max_features.argtypes = [C.c_void_p]
     L.aria_orb_kp_capacity.argtypes = [C.c_void_p]
+    L.aria_orb_rows_needed.argtypes = [C.c_void_p]
+    L.aria_orb_fetch_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.aria_orb_level_info.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_float)]
     L.aria_orb_resize_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]

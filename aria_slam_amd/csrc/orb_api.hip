@@ -29,13 +29,16 @@ struct aria_orb_s {
     int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 0;
     int band_qpct0 = 10;            // survivor-queue size of the band kernel at level 0 (% of a workgroup's pixels); self-tuned
     long long slow_blocks = 0;      // band-kernel workgroups that overflowed their queue since the last reset
+    int last_n = -1;                // keypoints of the last completed single-frame extraction (still in the pinned buffers)
+    int rows_needed = 0;            // rows the largest frame of the last checked batch call needed when kp_cap was too small
 
     Plan plan{};            // plan of the most recent (width, height)
     bool plan_valid = false;
     std::vector<uint32_t> tab_host;
     std::vector<int> bands_host;
     DeviceScratch D{};
-    int kp_cap = 0;         // rows of the internal single-frame output buffers
+    int kp_cap = 0;         // rows of the internal single-frame output buffers (grows when a tie storm needs more)
+    int plan_rows = 0;      // sum over levels of (quota + tie slack): what aria_orb_kp_capacity() reports
 
     // single-frame host path
     uint8_t* d_img = nullptr;
@@ -61,6 +64,7 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 void free_scratch(aria_orb_s* h) {
     hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand); hipFree(h->D.cand_cnt);
     hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.pyr_bands); hipFree(h->D.err);
+    hipFree(h->D.ovf); hipFree(h->D.ovf_items); hipFree(h->D.ovf_keys); hipFree(h->D.osel);
     hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_count);
     if (h->h_img) hipHostFree(h->h_img);
     if (h->h_kps) hipHostFree(h->h_kps);
@@ -91,6 +95,7 @@ int alloc_scratch(aria_orb_s* h) {
     if (rc != ARIA_OK) return rc;
     const size_t B = (size_t)h->max_batch;
     h->kp_cap = mp.sel_frame_entries;
+    h->plan_rows = mp.sel_frame_entries;
     ARIA_HIP(hipMalloc(&h->D.raw, std::max<size_t>(mp.raw_frame_bytes * B, 256)));
     ARIA_HIP(hipMalloc(&h->D.blur, std::max<size_t>(mp.blur_frame_bytes * B, 256)));
     ARIA_HIP(hipMalloc(&h->D.cand, sizeof(uint32_t) * (size_t)mp.cand_frame_entries * B));
@@ -100,8 +105,21 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
     h->bands_host.assign((size_t)((h->max_h + 7) / 8) * kLevels * 4 + 64, 0);
     ARIA_HIP(hipMalloc(&h->D.pyr_bands, sizeof(int) * h->bands_host.size()));
-    ARIA_HIP(hipMalloc(&h->D.err, 2 * sizeof(int)));     // [0] deferred error bits, [1] band-kernel slow-path blocks
-    ARIA_HIP(hipMemset(h->D.err, 0, 2 * sizeof(int)));
+    // [0] deferred error bits, [1] band-kernel slow-path blocks, [2] rows needed by the largest frame that did not fit kp_cap
+    ARIA_HIP(hipMalloc(&h->D.err, 4 * sizeof(int)));
+    ARIA_HIP(hipMemset(h->D.err, 0, 4 * sizeof(int)));
+    // tie-storm arenas: room for the worst case of four whole frames per pass (every FAST candidate of every level tied)
+    {
+        long long per_frame = 0;
+        for (int l = 0; l < kLevels; l++) { long long np = 1; while (np < mp.lv[l].cand_cap) np <<= 1; per_frame += np; }
+        h->D.ovf_keys_cap = 4 * per_frame;
+        h->D.osel_cap = (int)std::min<long long>(4 * (long long)mp.cand_frame_entries + 64, 1ll << 24);
+        ARIA_HIP(hipMalloc(&h->D.ovf, 4 * sizeof(int)));
+        ARIA_HIP(hipMemset(h->D.ovf, 0, 4 * sizeof(int)));
+        ARIA_HIP(hipMalloc(&h->D.ovf_items, sizeof(int2) * kOvfItems));
+        ARIA_HIP(hipMalloc(&h->D.ovf_keys, sizeof(unsigned long long) * (size_t)h->D.ovf_keys_cap));
+        ARIA_HIP(hipMalloc(&h->D.osel, sizeof(uint4) * (size_t)h->D.osel_cap));
+    }
     const size_t img_bytes = (size_t)align_up(h->max_w, 16) * h->max_h;
     ARIA_HIP(hipMalloc(&h->d_img, img_bytes));
     ARIA_HIP(hipHostMalloc(&h->h_img, img_bytes));
@@ -110,7 +128,7 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->d_count, sizeof(int)));
     ARIA_HIP(hipHostMalloc(&h->h_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
     ARIA_HIP(hipHostMalloc(&h->h_desc, 32 * (size_t)h->kp_cap));
-    ARIA_HIP(hipHostMalloc(&h->h_count, 4 * sizeof(int)));
+    ARIA_HIP(hipHostMalloc(&h->h_count, 8 * sizeof(int)));
     h->plan_valid = false;
     return ARIA_OK;
 }
@@ -137,6 +155,8 @@ int ensure_plan(aria_orb_s* h, int w, int ht) {
     return ARIA_OK;
 }
 
+int launch_single(aria_orb_s* h);
+
 int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, int stride) {
     if (!image || stride < width) return ARIA_E_INVALID;
     int rc = ensure_plan(h, width, height);
@@ -147,23 +167,53 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1, (pitch % 16 == 0 && ((int64_t)pitch * height) % 16 == 0) ? 1 : 0};
     h->last_src = S;
     h->have_last = true;
-    launch_extract_chunk(h->plan, S, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof, h->ctx);
+    return launch_single(h);
+}
+
+// Internal single-frame output buffers (rows = kp_cap). A tie storm can return more keypoints than the plan's slots
+// (OpenCV keeps every tie): the buffers then grow to what the frame needs and the frame is run again.
+int alloc_io(aria_orb_s* h, int rows) {
+    hipFree(h->d_kps); hipFree(h->d_desc);
+    if (h->h_kps) hipHostFree(h->h_kps);
+    if (h->h_desc) hipHostFree(h->h_desc);
+    h->d_kps = nullptr; h->d_desc = nullptr; h->h_kps = nullptr; h->h_desc = nullptr;
+    h->kp_cap = rows;
+    ARIA_HIP(hipMalloc(&h->d_kps, sizeof(aria_keypoint) * (size_t)rows));
+    ARIA_HIP(hipMalloc(&h->d_desc, 32 * (size_t)rows));
+    ARIA_HIP(hipHostMalloc(&h->h_kps, sizeof(aria_keypoint) * (size_t)rows));
+    ARIA_HIP(hipHostMalloc(&h->h_desc, 32 * (size_t)rows));
+    return ARIA_OK;
+}
+
+int launch_single(aria_orb_s* h) {
+    launch_extract_chunk(h->plan, h->last_src, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof, h->ctx);
     ARIA_HIP(hipGetLastError());
     ARIA_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
     ARIA_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, 32 * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
     ARIA_HIP(hipMemcpyAsync(&h->h_count[0], h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemcpyAsync(&h->h_count[1], h->D.err, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemsetAsync(h->D.err, 0, 2 * sizeof(int), h->stream));
+    ARIA_HIP(hipMemcpyAsync(&h->h_count[1], h->D.err, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
     return ARIA_OK;
 }
 
 int finish_single(aria_orb_s* h, aria_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     ARIA_HIP(hipStreamSynchronize(h->stream));
+    if ((h->h_count[1] & ERRBIT_KPCAP) && h->h_count[3] > h->kp_cap) {
+        // the frame has more keypoints than the internal buffers hold (ties): grow them and run the frame again
+        // (its image is still in the handle's device copy)
+        const int need = (h->h_count[3] + 63) & ~63;
+        int rc = alloc_io(h, need);
+        if (rc != ARIA_OK) return rc;
+        rc = launch_single(h);
+        if (rc != ARIA_OK) return rc;
+        ARIA_HIP(hipStreamSynchronize(h->stream));
+    }
     const int errbits = h->h_count[1];
     note_slow_blocks(h, h->h_count[2]);
     int st = errbits_to_status(errbits & ~ERRBIT_KPCAP);
     if (st != ARIA_OK) { if (n_out) *n_out = 0; return st; }
-    const int n = h->h_count[0];
+    const int n = (errbits & ERRBIT_KPCAP) ? std::max(h->h_count[3], h->h_count[0]) : h->h_count[0];
+    h->last_n = n;
     if (n_out) *n_out = n;
     if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
     if (n > 0) {
@@ -279,7 +329,8 @@ int aria_orb_set_max_features(aria_orb_t h, int n) {
 }
 
 int aria_orb_get_max_features(aria_orb_t h) { return h ? h->max_features : ARIA_E_INVALID; }
-int aria_orb_kp_capacity(aria_orb_t h) { return h ? h->kp_cap : ARIA_E_INVALID; }
+int aria_orb_kp_capacity(aria_orb_t h) { return h ? h->plan_rows : ARIA_E_INVALID; }
+int aria_orb_rows_needed(aria_orb_t h) { return h ? h->rows_needed : ARIA_E_INVALID; }
 void* aria_orb_stream(aria_orb_t h) { return h ? (void*)h->stream : nullptr; }
 
 int aria_orb_extract(aria_orb_t h, const uint8_t* image, int width, int height, int stride,
@@ -309,6 +360,20 @@ int aria_orb_sync(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descriptors, 
     return finish_single(h, keypoints, descriptors, cap, n_out);
 }
 
+int aria_orb_fetch_last(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out) {
+    if (!h || cap < 0) return ARIA_E_INVALID;
+    if (h->pending) return ARIA_E_BUSY;
+    if (h->last_n < 0) return ARIA_E_NOT_PENDING;
+    if (n_out) *n_out = h->last_n;
+    if (h->last_n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
+    if (h->last_n > 0) {
+        if (!keypoints || !descriptors) return ARIA_E_INVALID;
+        std::memcpy(keypoints, h->h_kps, sizeof(aria_keypoint) * (size_t)h->last_n);
+        std::memcpy(descriptors, h->h_desc, 32 * (size_t)h->last_n);
+    }
+    return ARIA_OK;
+}
+
 int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_frames, int width, int height,
                                   int64_t frame_stride, int row_stride, aria_keypoint* d_keypoints,
                                   uint8_t* d_descriptors, int* d_counts, int kp_cap) {
@@ -336,9 +401,10 @@ int aria_orb_check(aria_orb_t h) {
     if (!h) return ARIA_E_INVALID;
     ARIA_HIP(hipSetDevice(h->device));
     ARIA_HIP(hipStreamSynchronize(h->stream));
-    int two[2] = {0, 0};
-    ARIA_HIP(hipMemcpy(two, h->D.err, 2 * sizeof(int), hipMemcpyDeviceToHost));
-    if (two[0] || two[1]) ARIA_HIP(hipMemset(h->D.err, 0, 2 * sizeof(int)));
+    int two[4] = {0, 0, 0, 0};
+    ARIA_HIP(hipMemcpy(two, h->D.err, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (two[0] || two[1] || two[2]) ARIA_HIP(hipMemset(h->D.err, 0, 4 * sizeof(int)));
+    h->rows_needed = two[2];
     note_slow_blocks(h, two[1]);
     return errbits_to_status(two[0]);
 }

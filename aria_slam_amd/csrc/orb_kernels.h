@@ -32,6 +32,14 @@ struct DeviceScratch {
     uint32_t* tab;       // resize coefficient tables (ofs | c1 << 16)
     int* pyr_bands;      // [pyr_nbands][8][4] row ranges of the fused pyramid kernel
     int* err;            // deferred error bits
+    // tie-storm fallback (k_select_ovf): work list of (frame, level) pairs whose ties overflow k_select's LDS capacities,
+    // a key arena for the global-memory sort and an arena of selected keypoints beyond a level's regular slots
+    int* ovf;            // [0] items, [1] osel entries used, [2..3] key-arena entries used (64-bit)
+    int2* ovf_items;     // [kOvfItems]
+    unsigned long long* ovf_keys;
+    long long ovf_keys_cap;
+    uint4* osel;
+    int osel_cap;
 };
 
 // Optional per-stage timing (bench.py's roofline figure). HIP event pairs bracket each stage on the launch stream;

@@ -683,7 +683,8 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
 __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint4* __restrict__ sel, int* __restrict__ sel_cnt,
-                                                int* __restrict__ err, unsigned long long* __restrict__ stamps) {
+                                                int* __restrict__ err, unsigned long long* __restrict__ stamps,
+                                                int* __restrict__ ovf, int2* __restrict__ ovf_items) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     SSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
@@ -792,8 +793,15 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     SSTAMP(3);
     int n1 = s_misc[1];
     if (n1 > kSortCap) {
-        if (tid == 0) atomicOr(err, ERRBIT_SORT_OVERFLOW);
-        n1 = kSortCap;
+        // more candidates tie at the FAST cut than the LDS sort holds (a tie storm: checkerboards, synthetic patterns).
+        // OpenCV's retainBest keeps them all, so this (frame, level) is redone by k_select_ovf in global memory.
+        if (tid == 0) {
+            sel_cnt[frame * kLevels + l] = 0;
+            const int it = atomicAdd(&ovf[0], 1);
+            if (it < kOvfItems) ovf_items[it] = make_int2(frame, l);
+            else atomicOr(err, ERRBIT_SORT_OVERFLOW);
+        }
+        return;
     }
     int np = 1;
     while (np < n1) np <<= 1;
@@ -854,9 +862,14 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         __syncthreads();
         n2 = q + s_misc[2];
     }
-    if (n2 > g.sel_cap) {
-        if (tid == 0) atomicOr(err, ERRBIT_SEL_OVERFLOW);
-        n2 = g.sel_cap;
+    if (n2 > g.sel_cap) {      // more ties at the Harris cut than the level's slots hold: same fallback
+        if (tid == 0) {
+            sel_cnt[frame * kLevels + l] = 0;
+            const int it = atomicAdd(&ovf[0], 1);
+            if (it < kOvfItems) ovf_items[it] = make_int2(frame, l);
+            else atomicOr(err, ERRBIT_SEL_OVERFLOW);
+        }
+        return;
     }
     // Emit in raster order of 32 x 32-px tiles (counting sort, order inside a tile arbitrary), each record carrying its rank i in
     // the canonical order: k_describe then works on spatially close keypoints at the same time -- their 37-row
@@ -909,6 +922,139 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     if (tid == 0) sel_cnt[frame * kLevels + l] = n2;
     SSTAMP(5);
 #undef SSTAMP
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a6.3-a6.5 for the (frame, level) pairs whose ties did not fit k_select's LDS capacities: the same selection --
+// retainBest(2q) on the FAST score, Harris, retainBest(q) on Harris, ties kept at both cuts (keypoint.cpp
+// KeyPointsFilter::retainBest) -- with the keys in a global-memory arena: histogram cut, Harris keys, a bitonic sort
+// by one workgroup in global memory, then the selected keypoints go to the level's regular slots (first sel_cap) and to
+// the overflow arena `osel` (the rest, in blocks of four entries of one (frame, level): k_describe's arena pass).
+// Slow (milliseconds per item) and rare by construction; what matters is that the result equals the reference's.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ovf_ld(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // bypasses this CU's L1: other waves' stores
+}
+__device__ __forceinline__ void ovf_st(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                    const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                                    uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                                    int* __restrict__ ovf, const int2* __restrict__ ovf_items,
+                                                    unsigned long long* __restrict__ keys, long long keys_cap,
+                                                    uint4* __restrict__ osel, int osel_cap) {
+    __shared__ int s_hist[256];
+    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena base (-1: none), [4] osel base
+    const int tid = threadIdx.x;
+    const int n_items = min(ovf[0], kOvfItems);
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int frame = ovf_items[it].x, l = ovf_items[it].y;
+        const LevelGeom g = P.lv[l];
+        const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
+        const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
+        const int q = g.quota;
+        __syncthreads();
+        s_hist[tid] = 0;
+        if (tid < 8) s_misc[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[clist[i] >> 22], 1);
+        __syncthreads();
+        if (tid == 0) {   // retainBest(2q): largest score whose suffix count reaches 2q (0 if there are at most 2q)
+            int thr = 0, n1 = n;
+            if (n > 2 * q) {
+                int cum = 0;
+                for (int sc = 255; sc >= 0; sc--) {
+                    cum += s_hist[sc];
+                    if (cum >= 2 * q) { thr = sc; n1 = cum; break; }
+                }
+            }
+            long long np = 1;
+            while (np < n1) np <<= 1;
+            const long long base = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(ovf + 2), (unsigned long long)np);
+            s_misc[0] = thr;
+            if (base + np > keys_cap) { atomicOr(err, ERRBIT_SORT_OVERFLOW); s_misc[3] = -1; }
+            else { s_misc[3] = 0; }
+            reinterpret_cast<long long*>(s_misc + 6)[0] = base;
+            s_misc[5] = n1;
+        }
+        __syncthreads();
+        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; continue; }
+        const int thr = s_misc[0], n1 = s_misc[5];
+        unsigned long long* K = keys + reinterpret_cast<long long*>(s_misc + 6)[0];
+        long long np = 1;
+        while (np < n1) np <<= 1;
+        int pitch;
+        const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            const int i = i0 + tid;
+            const uint32_t cd = i < n ? clist[i] : 0u;
+            const bool keep = i < n && (int)(cd >> 22) >= thr;
+            unsigned long long key = 0;
+            if (keep) {
+                const int x = cd & 0x7FF, y = (cd >> 11) & 0x7FF;
+                const float r = harris_response(img, pitch, x, y, (l > 0) || S.aligned4);
+                uint32_t u = __float_as_uint(r);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                key = ((unsigned long long)(~u) << 32) | ((uint32_t)y << 16) | (uint32_t)x;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(m));
+                base = __shfl(base, leader);
+                if (keep) ovf_st(&K[base + __popcll(m & ((1ull << lane) - 1ull))], key);
+            }
+        }
+        for (long long i = n1 + tid; i < np; i += 256) ovf_st(&K[i], ~0ull);
+        __syncthreads();
+        // bitonic sort in global memory, ascending on (~harris_order, y, x) == Harris descending, then y, then x
+        for (long long k = 2; k <= np; k <<= 1)
+            for (long long j = k >> 1; j > 0; j >>= 1) {
+                for (long long t = tid; t < (np >> 1); t += 256) {
+                    const long long a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+                    const unsigned long long xa = ovf_ld(&K[a]), xb = ovf_ld(&K[b]);
+                    if ((xa > xb) == ((a & k) == 0)) { ovf_st(&K[a], xb); ovf_st(&K[b], xa); }
+                }
+                __syncthreads();
+            }
+        // retainBest(quota) on Harris: first q plus everything tying with the q-th
+        int n2 = n1;
+        if (n1 > q) {
+            const uint32_t cut = (uint32_t)(ovf_ld(&K[q - 1]) >> 32);
+            for (int i = q + tid; i < n1; i += 256)
+                if ((uint32_t)(ovf_ld(&K[i]) >> 32) == cut) atomicAdd(&s_misc[2], 1);
+            __syncthreads();
+            n2 = q + s_misc[2];
+        }
+        const int extra = max(n2 - g.sel_cap, 0), extra4 = (extra + 3) & ~3;
+        if (tid == 0) {
+            int ob = 0;
+            if (extra4 > 0) {
+                ob = atomicAdd(&ovf[1], extra4);
+                if (ob + extra4 > osel_cap) { atomicOr(err, ERRBIT_SEL_OVERFLOW); ob = -1; }
+            }
+            s_misc[4] = ob;
+        }
+        __syncthreads();
+        const int ob = s_misc[4];
+        if (ob < 0) n2 = g.sel_cap;
+        uint4* out = sel + (int64_t)frame * P.sel_frame_entries + g.sel_off;
+        const uint32_t tag = (uint32_t)frame | ((uint32_t)l << 24);
+        for (int i = tid; i < n2; i += 256) {
+            const unsigned long long kk = ovf_ld(&K[i]);
+            uint32_t u = ~(uint32_t)(kk >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+            const uint4 rec = make_uint4((uint32_t)kk, u, (uint32_t)i, tag);
+            if (i < g.sel_cap) out[i] = rec;
+            else osel[ob + (i - g.sel_cap)] = rec;
+        }
+        if (ob >= 0)
+            for (int i = extra + tid; i < extra4; i += 256) osel[ob + i] = make_uint4(0u, 0u, 0xFFFFFFFFu, tag);   // padding
+        if (tid == 0) sel_cnt[frame * kLevels + l] = n2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1011,7 +1157,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err, int n_frames, int blocks_per_frame,
-                                                  unsigned long long* __restrict__ stamps) {
+                                                  unsigned long long* __restrict__ stamps,
+                                                  const uint4* __restrict__ osel, const int* __restrict__ ovf, int osel_cap) {
     // diagnostic only (ARIA_DESC_STAMPS=1): s_memtime at the phase boundaries of every wave
 #define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * kDescWaves + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     DSTAMP(0);
@@ -1019,32 +1166,59 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     // reduced -- the blurred 37 x 64 window, which has been waiting in registers since both were requested together.
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[kDescKp][kDescRows * kDescPitch];
     uint8_t (*s_raw)[kDescRows * kDescPitch] = s_patch;
-    // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
-    // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int frame = (j / blocks_per_frame) * 8 + xcd;
-    if (frame >= n_frames) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
-    const int slot0 = (j % blocks_per_frame) * kDescKp + wv * 4;      // first of this wave's four slots (one level)
-    const int* cnt = sel_cnt + frame * kLevels;
-    int l = 0, base = 0, total = 0;
+    // regular pass: one trip (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks
+    const int n_blk = osel ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : (int)gridDim.x;
+    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    int frame, l = 0, base = 0, nk;
+    uint4 sv;
+    if (osel == nullptr) {
+        // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
+        // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
+        const int xcd = blk & 7, j = blk >> 3;
+        frame = (j / blocks_per_frame) * 8 + xcd;
+        if (frame >= n_frames) continue;
+        const int slot0 = (j % blocks_per_frame) * kDescKp + wv * 4;      // first of this wave's four slots (one level)
+        const int* cnt = sel_cnt + frame * kLevels;
+        int total = 0;
 #pragma unroll
-    for (int i = 0; i < kLevels; i++) {
-        const int ci = cnt[i];
-        if (i > 0 && slot0 >= P.lv[i].sel_off) { l = i; base = total; }
-        total += ci;
+        for (int i = 0; i < kLevels; i++) {
+            const int ci = cnt[i];
+            if (i > 0 && slot0 >= P.lv[i].sel_off) { l = i; base = total; }
+            total += ci;
+        }
+        // counts stay within kp_cap (the matcher trusts them); a frame that needs more rows raises ERRBIT_KPCAP below and
+        // leaves the number it needs in err[2]
+        if (slot0 == 0 && lane == 0) {
+            counts[frame] = min(total, kp_cap);
+            if (total > kp_cap) atomicMax(err + 2, total);
+        }
+        if (slot0 >= P.sel_frame_entries) continue;
+        l = __builtin_amdgcn_readfirstlane(l);     // the wave's four slots are in one level: keep the level geometry scalar
+        const int i0 = slot0 - P.lv[l].sel_off;
+        nk = min(4, min(cnt[l], P.lv[l].sel_cap) - i0);                    // valid keypoints of this wave
+        if (nk <= 0) continue;
+        // slots hold the level's keypoints in tile order; the record says which row of the output it is
+        sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
+    } else {
+        // arena pass: keypoints of tie-storm levels beyond the level's regular slots (k_select_ovf), in blocks of four
+        // entries of one (frame, level); .w = frame | level << 24, rank 0xFFFFFFFF = padding (at the end of a block)
+        const int e0 = blk * kDescKp + wv * 4;
+        if (e0 >= min(ovf[1], osel_cap)) continue;
+        const uint4 mine = osel[e0 + grp];
+        const unsigned long long vm = __ballot(mine.z != 0xFFFFFFFFu && l16 == 0);
+        nk = __popcll(vm);
+        if (nk <= 0) continue;
+        const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine.w);
+        frame = (int)(tag & 0xFFFFFFu);
+        l = (int)(tag >> 24);
+        const int* cnt = sel_cnt + frame * kLevels;
+        for (int i = 0; i < l; i++) base += cnt[i];
+        sv = osel[e0 + min(grp, nk - 1)];
     }
-    if (slot0 == 0 && lane == 0) counts[frame] = min(total, kp_cap);
-    if (slot0 >= P.sel_frame_entries) return;
-    l = __builtin_amdgcn_readfirstlane(l);     // the wave's four slots are in one level: keep the level geometry scalar
     const LevelGeom g = P.lv[l];
-    const int i0 = slot0 - g.sel_off;
-    const int nk = min(4, cnt[l] - i0);                                // valid keypoints of this wave
-    if (nk <= 0) return;
     const bool valid = grp < nk;
-    // slots hold the level's keypoints in tile order; the record says which row of the output it is
-    const uint4 sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
     const int oidx = base + (int)sv.z;
     const bool fits = oidx < kp_cap;
     if (valid && !fits && l16 == 0) atomicOr(err, ERRBIT_KPCAP);
@@ -1216,6 +1390,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
             kps[orow] = k;
         }
     }
+    }
     DSTAMP(6);
 #undef DSTAMP
 }
@@ -1323,6 +1498,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     const EnvConfig& E = env_config();
     if (prof && prof->enabled) prof->frames += n_frames;
     hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
+    hipMemsetAsync(D.ovf, 0, 4 * sizeof(int), st);
 
     // ---- a6.1 pyramid ----
     // Default: no pass of its own -- the FAST/blur launch of level l writes the raw rows of level l+1 from the rows it
@@ -1383,7 +1559,10 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;
     if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
     ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
-                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp);
+                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items);
+    // tie-storm fallback: a fixed small grid that finds the work list empty on ordinary images
+    ARIA_LAUNCH(prof, k_select_ovf, dim3(64), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err,
+                D.ovf, D.ovf_items, D.ovf_keys, D.ovf_keys_cap, D.osel, D.osel_cap);
     if (sstp) {
         hipStreamSynchronize(st);
         std::vector<unsigned long long> hs((size_t)n_frames * kLevels * 8);
@@ -1413,7 +1592,12 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
         ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
-                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp);
+                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
+                    (const int*)nullptr, 0);
+        // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
+        ARIA_LAUNCH(prof, k_describe, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
+                    D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
+                    (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
         if (stp) {
             hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(nwaves * 8);

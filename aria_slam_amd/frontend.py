@@ -68,9 +68,20 @@ class OrbHipExtractor:
         kps = np.empty(cap, KP_DTYPE)
         desc = np.empty((cap, 32), np.uint8)
         n = C.c_int()
-        check(self._L.aria_orb_extract(self._h, img.ctypes.data, width, height, width, kps.ctypes.data,
-                                       desc.ctypes.data, cap, C.byref(n)), "aria_orb_extract")
+        st = self._L.aria_orb_extract(self._h, img.ctypes.data, width, height, width, kps.ctypes.data,
+                                      desc.ctypes.data, cap, C.byref(n))
+        if st == _lib.ARIA_E_OUTPUT_TOO_SMALL:
+            kps, desc = self._fetch_last(n.value)       # a tie storm returned more keypoints than the plan's rows
+        else:
+            check(st, "aria_orb_extract")
         return self._fill(frame, width, height, kps[:n.value].copy(), desc[:n.value].copy())
+
+    def _fetch_last(self, rows):
+        kps = np.empty(rows, KP_DTYPE)
+        desc = np.empty((rows, 32), np.uint8)
+        n = C.c_int()
+        check(self._L.aria_orb_fetch_last(self._h, kps.ctypes.data, desc.ctypes.data, rows, C.byref(n)), "aria_orb_fetch_last")
+        return kps, desc
 
     def extractAsync(self, image_data, width=None, height=None, frame=None):
         img = np.ascontiguousarray(image_data, np.uint8)
@@ -89,7 +100,11 @@ class OrbHipExtractor:
         kps = np.empty(cap, KP_DTYPE)
         desc = np.empty((cap, 32), np.uint8)
         n = C.c_int()
-        check(self._L.aria_orb_sync(self._h, kps.ctypes.data, desc.ctypes.data, cap, C.byref(n)), "aria_orb_sync")
+        st = self._L.aria_orb_sync(self._h, kps.ctypes.data, desc.ctypes.data, cap, C.byref(n))
+        if st == _lib.ARIA_E_OUTPUT_TOO_SMALL:
+            kps, desc = self._fetch_last(n.value)
+        else:
+            check(st, "aria_orb_sync")
         return self._fill(frame, width, height, kps[:n.value].copy(), desc[:n.value].copy())
 
     def setMaxFeatures(self, n):
@@ -112,6 +127,10 @@ class OrbHipExtractor:
 
     def check(self):
         check(self._L.aria_orb_check(self._h), "aria_orb_check")
+
+    def rows_needed(self):
+        """Rows the largest frame of the last checked batch call needed when kp_cap was too small (else 0)."""
+        return self._L.aria_orb_rows_needed(self._h)
 
     def slow_path_blocks(self, reset=False):
         return self._L.aria_orb_slow_path_blocks(self._h, int(reset))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ARIA_ORB_HIP_ABI_VERSION 1
+#define ARIA_ORB_HIP_ABI_VERSION 2
 
 typedef enum {
     ARIA_OK = 0,
@@ -41,8 +41,12 @@ typedef enum {
     ARIA_E_OOM = -3,              /* device or host allocation failed                                       */
     ARIA_E_TOO_LARGE = -4,        /* image larger than the handle was created for                           */
     ARIA_E_OUTPUT_TOO_SMALL = -5, /* caller's keypoint/match capacity is smaller than the result            */
-    ARIA_E_OVERFLOW = -6,         /* an internal candidate/sort buffer overflowed (pathological image);
-                                     results are NOT valid. Raise cand_cap_scale and retry.                 */
+    ARIA_E_OVERFLOW = -6,         /* an internal buffer overflowed; results are NOT valid. Either a FAST candidate
+                                     list (only possible with cand_cap_scale > 0: raise it or use 0), or the
+                                     tie-storm arenas: selection ties beyond the on-chip capacities are handled
+                                     in global memory (k_select_ovf), whose arenas hold the worst case of four
+                                     whole frames per internal pass -- a batch with more all-tied frames than
+                                     that needs a smaller max_batch.                                         */
     ARIA_E_BUSY = -7,             /* extract_async called while another async extract is pending            */
     ARIA_E_NOT_PENDING = -8,      /* sync called with nothing pending (treated as a no-op by the adapter)   */
     ARIA_E_HIP = -9,              /* a HIP runtime call failed (bad pointer, bad stream, ...): aria_last_hip_error() */
@@ -88,8 +92,16 @@ void aria_orb_destroy(aria_orb_t h);
  * OrbCudaExtractor.cpp:212-216). All other ORB parameters keep the reference's values. */
 int aria_orb_set_max_features(aria_orb_t h, int n);
 int aria_orb_get_max_features(aria_orb_t h);
-/* Rows to allocate per frame for keypoints/descriptors so that tie overshoot still fits. */
+/* Rows to allocate per frame for keypoints/descriptors: sum over levels of (quota + 64 rows of tie slack). OpenCV's
+ * retainBest keeps EVERY keypoint tying with the last kept one, so a tie storm (checkerboards, synthetic
+ * patterns) can return more: the host entry points then report ARIA_E_OUTPUT_TOO_SMALL with *n_out = rows required
+ * (retry with that capacity, or call aria_orb_fetch_last), the batch entry point makes aria_orb_check return
+ * ARIA_E_OUTPUT_TOO_SMALL and aria_orb_rows_needed() tell the rows its largest frame needs. */
 int aria_orb_kp_capacity(aria_orb_t h);
+int aria_orb_rows_needed(aria_orb_t h);
+/* Copies the result of the last completed aria_orb_extract / aria_orb_sync out again (it stays in the handle until the
+ * next extraction): what a caller uses after ARIA_E_OUTPUT_TOO_SMALL instead of extracting again. */
+int aria_orb_fetch_last(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out);
 
 /* IFeatureExtractor::extract (IFeatureExtractor.hpp:18-23; OrbCudaExtractor.cpp:64-128). Host buffers.
  * image is borrowed and never written; stride = bytes between rows (width for the reference's packed Mat,

@@ -114,12 +114,9 @@ def test_degenerate_images(aria, oracle, kind):
     h, w = img.shape
     e = _ext(aria, nf=500, w=w, h=h)
     try:
-        try:
-            f = e.extract(img)
-        except aria.AriaError as err:
-            assert kind == "checker" and err.status == -6      # loud overflow is acceptable only for the tie storm
-            return
+        f = e.extract(img)          # the checkerboard is a tie storm: every tie is kept, as retainBest does
         ok, od = oracle.orb_extract(img, oracle.default_params(500), cap=20000)
+
         assert len(f["keypoints"]) == len(ok)
         assert f["keypoints"].tobytes() == ok.tobytes() and np.array_equal(f["descriptors"], od)
         if kind == "flat":
@@ -478,7 +475,7 @@ def test_profiling_stage_masks(aria, torch_cuda):
         run()
         pe, _ = e.get_profile()
         pm, _ = m.get_profile()
-        assert pe["select"][1] == 1 and pe["describe"][1] == 1 and pe["fast_blur"][1] == 8
+        assert pe["select"][1] == 2 and pe["describe"][1] == 2 and pe["fast_blur"][1] == 8   # + the tie-storm fallback launches
         assert pe["resize"][1] in (0, 7)          # 0: pyramid fused into the FAST/blur launches (default)
         assert pm["ratio_compact"][1] == 1
         e.set_profiling(False)
@@ -592,3 +589,82 @@ def test_two_handles_from_two_host_threads(aria, oracle):
             assert fa["keypoints"].tobytes() == ka.tobytes() and np.array_equal(fa["descriptors"], da)
             assert fb["keypoints"].tobytes() == kb.tobytes() and np.array_equal(fb["descriptors"], db)
             assert got.tobytes() == want.tobytes()
+
+
+# ---- tie storms: OpenCV's retainBest keeps every tie (reference call site src/legacy/Frame.cpp:45-49) ---------
+def _checker(w, h, cell):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return (((xx // cell + yy // cell) & 1) * 200 + 20).astype(np.uint8)
+
+
+def _dots(w, h, pitch):
+    """Single bright pixels on a flat background, on a regular grid: every dot is a FAST corner with the same score and
+    the same Harris response at level 0 -- exact ties at both of retainBest's cuts."""
+    img = np.full((h, w), 50, np.uint8)
+    img[pitch // 2::pitch, pitch // 2::pitch] = 255
+    return img
+
+
+@pytest.mark.parametrize("kind,w,h,par,nf", [("checker", 320, 240, 8, 500), ("checker", 640, 480, 8, 2000),
+                                             ("dots", 640, 480, 16, 2000), ("dots", 640, 480, 7, 2000),
+                                             ("dots", 752, 480, 11, 1000)])
+def test_tie_storm_single_frame_equals_oracle(aria, oracle, kind, w, h, par, nf):
+    """Tie storms: checkerboards (thousands of candidates with one FAST score: more than the on-chip sort holds) and dot
+    grids (every level-0 keypoint ties in FAST score AND Harris response, so retainBest keeps them all and the frame
+    returns more keypoints than the plan has rows). The global-memory fallback (k_select_ovf + the arena pass of
+    k_describe) must return exactly the oracle's keypoints, in canonical order, through the host entry points."""
+    img = _checker(w, h, par) if kind == "checker" else _dots(w, h, par)
+    e = _ext(aria, nf=nf, w=w, h=h)
+    try:
+        ok, od = oracle.orb_extract(img, oracle.default_params(nf), cap=400000)
+        if kind == "dots" and par < 16:
+            assert len(ok) > e.kp_capacity()                    # more keypoints than the plan's rows
+        f = e.extract(img)
+        assert len(f["keypoints"]) == len(ok)
+        assert f["keypoints"].tobytes() == ok.tobytes() and np.array_equal(f["descriptors"], od)
+        e.extractAsync(img)                                     # the async form takes the same route
+        g = e.sync()
+        assert g["keypoints"].tobytes() == ok.tobytes() and np.array_equal(g["descriptors"], od)
+        a, _ = aria.synth_frame_pair(5, w, h)                   # and the handle is fine afterwards
+        fa = e.extract(a)
+        ka, da = oracle.orb_extract(a, oracle.default_params(nf))
+        assert fa["keypoints"].tobytes() == ka.tobytes() and np.array_equal(fa["descriptors"], da)
+    finally:
+        e.close()
+
+
+def test_tie_storm_inside_a_device_batch(aria, oracle, torch_cuda):
+    """Batch entry point: a dot grid (tie storm) between two ordinary frames. With the plan's kp_cap the call reports
+    ARIA_E_OUTPUT_TOO_SMALL and the rows the frame needs; with that capacity all three frames equal the oracle."""
+    torch = torch_cuda
+    w, h, nf = 320, 240, 300
+    dev = torch.device("cuda", 0)
+    imgs = np.stack([aria.synth_frame_pair(8, w, h)[0], _dots(w, h, 7), aria.synth_frame_pair(9, w, h)[1]])
+    want = [oracle.orb_extract(im, oracle.default_params(nf), cap=200000) for im in imgs]
+    s = torch.cuda.Stream(device=dev)
+    e = _ext(aria, nf=nf, w=w, h=h, max_batch=3, stream=s.cuda_stream)
+    try:
+        d_img = torch.from_numpy(imgs).to(dev)
+        for attempt in range(2):
+            cap = e.kp_capacity() if attempt == 0 else need
+            kps = torch.zeros((3, cap, 24), dtype=torch.uint8, device=dev)
+            desc = torch.zeros((3, cap, 32), dtype=torch.uint8, device=dev)
+            cnt = torch.zeros((3,), dtype=torch.int32, device=dev)
+            with torch.cuda.stream(s):
+                e.extract_batch_device(d_img, 3, w, h, kps, desc, cnt, cap)
+            if attempt == 0:
+                with pytest.raises(aria.AriaError) as ex:
+                    e.check()
+                assert ex.value.status == -5
+                need = e.rows_needed()
+                assert need == len(want[1][0])
+            else:
+                e.check()
+        cnt = cnt.cpu().numpy()
+        for f in range(3):
+            ok, od = want[f]
+            assert cnt[f] == len(ok)
+            assert kps[f, :cnt[f]].cpu().numpy().tobytes() == ok.tobytes()
+            assert np.array_equal(desc[f, :cnt[f]].cpu().numpy(), od)
+    finally:
+        e.close()
