@@ -28,6 +28,8 @@ EXPORTS = [
     "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
     "aria_matcher_knn2", "aria_matcher_match_batch_device", "aria_matcher_match_db_device",
     "aria_matcher_stream", "aria_matcher_sync", "aria_synth_frame_pair", "aria_synth_sequence",
+    "aria_matcher_match_multi", "aria_matcher_count_good_multi", "aria_kfdb_create", "aria_kfdb_destroy", "aria_kfdb_size",
+    "aria_kfdb_add", "aria_kfdb_add_device", "aria_kfdb_info", "aria_kfdb_fetch", "aria_kfdb_scan",
 ]
 
 

@@ -208,6 +208,12 @@ struct aria_matcher_s {
     aria_match* h_m = nullptr;      // pinned
     int* h_n = nullptr;             // pinned [0] n, [1] err
     int* h_idx = nullptr;           // pinned
+    // one-query-against-many path (IMatcher::matchMultiple / loop candidates): grow-only staging
+    uint8_t* d_multi = nullptr;     // [n_cand][multi_rows * 32]
+    int* d_mcnt = nullptr;          // [n_cand] rows per candidate, then [n_cand] results (matches or good counts)
+    aria_match* d_mm = nullptr;     // [n_cand][max_query]
+    size_t multi_bytes = 0, mm_entries = 0;
+    int mcnt_cap = 0;
     // optional stage timing (HIP events on the launch stream)
     bool prof_enabled = false;
     unsigned prof_mask = ~0u;       // bit s: bracket stage s (0 knn2, 1 ratio_compact)
@@ -272,7 +278,7 @@ int ensure_keys(aria_matcher_s* m, size_t entries) {
 
 void matcher_free(aria_matcher_s* m) {
     hipFree(m->d_keys); hipFree(m->d_err); hipFree(m->d_q); hipFree(m->d_t); hipFree(m->d_m); hipFree(m->d_n);
-    hipFree(m->d_idx);
+    hipFree(m->d_idx); hipFree(m->d_multi); hipFree(m->d_mcnt); hipFree(m->d_mm);
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->h_m) hipHostFree(m->h_m);
     if (m->h_n) hipHostFree(m->h_n);
@@ -487,6 +493,213 @@ int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int n
     launch_knn2(m, 1, nq, n_kf, d_query, nullptr, nq, d_db, d_kf_counts, 0, (int64_t)0, desc_stride,
                 nullptr, 0, ratio, d_good, (int)(desc_stride / 32));
     ARIA_HIP(hipGetLastError());
+    return ARIA_OK;
+}
+
+
+// ---- one query against many candidates ----------------------------------------------------------------------
+namespace {
+// Uploads the query and every candidate's descriptors (candidate c at d_multi + c * rows * 32) and the row counts.
+int stage_multi(aria_matcher_s* m, const uint8_t* q, int nq, const uint8_t* const* trains, const int* nts, int n_cand,
+                int* rows_out) {
+    int rows = 1;
+    for (int c = 0; c < n_cand; c++) {
+        if (nts[c] < 0 || (nts[c] > 0 && !trains[c])) return ARIA_E_INVALID;
+        rows = std::max(rows, nts[c]);
+    }
+    if (rows > 65535) return ARIA_E_TOO_LARGE;
+    if (nq > m->max_query) return ARIA_E_TOO_LARGE;
+    const size_t need = (size_t)n_cand * rows * 32;
+    if (need > m->multi_bytes) {
+        ARIA_HIP(hipStreamSynchronize(m->stream));
+        hipFree(m->d_multi); m->d_multi = nullptr; m->multi_bytes = 0;
+        ARIA_HIP(hipMalloc(&m->d_multi, need));
+        m->multi_bytes = need;
+    }
+    if (n_cand > m->mcnt_cap) {
+        ARIA_HIP(hipStreamSynchronize(m->stream));
+        hipFree(m->d_mcnt); m->d_mcnt = nullptr; m->mcnt_cap = 0;
+        ARIA_HIP(hipMalloc(&m->d_mcnt, sizeof(int) * 2 * (size_t)n_cand));
+        m->mcnt_cap = n_cand;
+    }
+    std::memcpy(m->h_stage, q, (size_t)nq * 32);
+    ARIA_HIP(hipMemcpyAsync(m->d_q, m->h_stage, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    for (int c = 0; c < n_cand; c++)
+        if (nts[c] > 0)
+            ARIA_HIP(hipMemcpyAsync(m->d_multi + (size_t)c * rows * 32, trains[c], (size_t)nts[c] * 32, hipMemcpyHostToDevice, m->stream));
+    ARIA_HIP(hipMemcpyAsync(m->d_mcnt, nts, sizeof(int) * (size_t)n_cand, hipMemcpyHostToDevice, m->stream));
+    *rows_out = rows;
+    return ARIA_OK;
+}
+}  // namespace
+
+int aria_matcher_match_multi(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* const* trains, const int* nts,
+                             int n_cand, float ratio, aria_match* matches, int cap_per_cand, int* n_out) {
+    if (!m || nq < 0 || n_cand < 0 || cap_per_cand < 0 || (n_cand > 0 && (!trains || !nts || !n_out))) return ARIA_E_INVALID;
+    for (int c = 0; c < n_cand; c++) n_out[c] = 0;
+    if (n_cand == 0 || nq == 0) return ARIA_OK;            // CudaMatcher.cpp:35-37 for every candidate
+    if (!q) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(m->device));
+    int rows = 0;
+    int rc = stage_multi(m, q, nq, trains, nts, n_cand, &rows);
+    if (rc != ARIA_OK) return rc;
+    rc = ensure_keys(m, (size_t)n_cand * (size_t)m->max_query);
+    if (rc != ARIA_OK) return rc;
+    if ((size_t)n_cand * (size_t)m->max_query > m->mm_entries) {
+        ARIA_HIP(hipStreamSynchronize(m->stream));
+        hipFree(m->d_mm); m->d_mm = nullptr; m->mm_entries = 0;
+        ARIA_HIP(hipMalloc(&m->d_mm, sizeof(aria_match) * (size_t)n_cand * (size_t)m->max_query));
+        m->mm_entries = (size_t)n_cand * (size_t)m->max_query;
+    }
+    // one launch over all candidates: the query block is shared (stride 0), candidate c is train block c
+    launch_knn2(m, 0, nq, n_cand, m->d_q, nullptr, nq, m->d_multi, m->d_mcnt, 0, (int64_t)0, (int64_t)rows * 32, m->d_keys,
+                m->max_query, 0.0, nullptr, rows);
+    hipLaunchKernelGGL(k_ratio_compact, dim3(n_cand), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
+                       m->d_mm, m->d_mcnt + n_cand, m->max_query, m->d_err);
+    ARIA_HIP(hipGetLastError());
+    std::vector<int> cnt((size_t)n_cand);
+    ARIA_HIP(hipMemcpyAsync(cnt.data(), m->d_mcnt + n_cand, sizeof(int) * (size_t)n_cand, hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    int status = ARIA_OK;
+    for (int c = 0; c < n_cand; c++) {
+        n_out[c] = cnt[(size_t)c];
+        if (cnt[(size_t)c] > cap_per_cand) { status = ARIA_E_OUTPUT_TOO_SMALL; continue; }
+        if (cnt[(size_t)c] > 0) {
+            if (!matches) return ARIA_E_INVALID;
+            ARIA_HIP(hipMemcpy(matches + (size_t)c * cap_per_cand, m->d_mm + (size_t)c * m->max_query,
+                               sizeof(aria_match) * (size_t)cnt[(size_t)c], hipMemcpyDeviceToHost));
+        }
+    }
+    return status;
+}
+
+int aria_matcher_count_good_multi(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* const* trains, const int* nts,
+                                  int n_cand, double ratio, int* good) {
+    if (!m || nq < 0 || n_cand < 0 || (n_cand > 0 && (!trains || !nts || !good))) return ARIA_E_INVALID;
+    for (int c = 0; c < n_cand; c++) good[c] = 0;
+    if (n_cand == 0 || nq == 0) return ARIA_OK;
+    if (!q) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(m->device));
+    int rows = 0;
+    int rc = stage_multi(m, q, nq, trains, nts, n_cand, &rows);
+    if (rc != ARIA_OK) return rc;
+    rc = aria_matcher_match_db_device(m, m->d_q, nq, m->d_multi, m->d_mcnt, n_cand, (int64_t)rows * 32, ratio, m->d_mcnt + n_cand);
+    if (rc != ARIA_OK) return rc;
+    ARIA_HIP(hipMemcpyAsync(good, m->d_mcnt + n_cand, sizeof(int) * (size_t)n_cand, hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    return ARIA_OK;
+}
+
+// ---- HBM-resident keyframe descriptor database (LoopClosureDetector's deque, src/legacy/LoopClosure.cpp:24-31) ----
+struct aria_kfdb_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int cap = 0, rows = 0;
+    int head = 0, n = 0;                 // ring: logical keyframe i lives in slot (head + i) % cap
+    uint8_t* d_desc = nullptr;           // [cap][rows * 32]
+    int* d_counts = nullptr;             // [cap]
+    int* d_good = nullptr;               // [cap]
+    std::vector<long long> ids;          // per slot
+    std::vector<int> counts;             // per slot (host mirror)
+};
+
+int aria_kfdb_create(int device, void* stream, int capacity, int rows, aria_kfdb_t* out) {
+    if (!out || capacity < 1 || rows < 1 || rows > 65535) return ARIA_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    ARIA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return ARIA_E_NO_DEVICE;
+    ARIA_HIP(hipSetDevice(device));
+    aria_kfdb_s* db = new (std::nothrow) aria_kfdb_s();
+    if (!db) return ARIA_E_OOM;
+    db->device = device; db->cap = capacity; db->rows = rows;
+    db->ids.assign((size_t)capacity, -1); db->counts.assign((size_t)capacity, 0);
+    if (stream) db->stream = (hipStream_t)stream;
+    else {
+        hipError_t e = hipStreamCreate(&db->stream);
+        if (e != hipSuccess) { delete db; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+        db->owns_stream = true;
+    }
+    hipError_t e = hipMalloc(&db->d_desc, (size_t)capacity * rows * 32);
+    if (e == hipSuccess) e = hipMalloc(&db->d_counts, sizeof(int) * (size_t)capacity);
+    if (e == hipSuccess) e = hipMalloc(&db->d_good, sizeof(int) * (size_t)capacity);
+    if (e == hipSuccess) e = hipMemset(db->d_counts, 0, sizeof(int) * (size_t)capacity);
+    if (e != hipSuccess) { aria_kfdb_destroy(db); return hip_fail(e, "aria_kfdb_create", __FILE__, __LINE__); }
+    *out = db;
+    return ARIA_OK;
+}
+
+void aria_kfdb_destroy(aria_kfdb_t db) {
+    if (!db) return;
+    hipSetDevice(db->device);
+    if (db->stream) hipStreamSynchronize(db->stream);
+    hipFree(db->d_desc); hipFree(db->d_counts); hipFree(db->d_good);
+    if (db->owns_stream && db->stream) hipStreamDestroy(db->stream);
+    delete db;
+}
+
+int aria_kfdb_size(aria_kfdb_t db) { return db ? db->n : ARIA_E_INVALID; }
+
+static int kfdb_add(aria_kfdb_s* db, long long id, const uint8_t* desc, int n, hipMemcpyKind kind) {
+    if (!db || n < 0 || (n > 0 && !desc)) return ARIA_E_INVALID;
+    if (n > db->rows) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(db->device));
+    int slot;
+    if (db->n == db->cap) { slot = db->head; db->head = (db->head + 1) % db->cap; }      // pop_front, LoopClosure.cpp:28-30
+    else { slot = (db->head + db->n) % db->cap; db->n++; }
+    if (n > 0) ARIA_HIP(hipMemcpyAsync(db->d_desc + (size_t)slot * db->rows * 32, desc, (size_t)n * 32, kind, db->stream));
+    ARIA_HIP(hipMemcpyAsync(db->d_counts + slot, &n, sizeof(int), hipMemcpyHostToDevice, db->stream));
+    ARIA_HIP(hipStreamSynchronize(db->stream));          // the caller may free its buffer; &n is a stack address
+    db->ids[(size_t)slot] = id;
+    db->counts[(size_t)slot] = n;
+    return ARIA_OK;
+}
+int aria_kfdb_add(aria_kfdb_t db, long long id, const uint8_t* desc, int n) { return kfdb_add(db, id, desc, n, hipMemcpyHostToDevice); }
+int aria_kfdb_add_device(aria_kfdb_t db, long long id, const uint8_t* d_desc, int n) { return kfdb_add(db, id, d_desc, n, hipMemcpyDeviceToDevice); }
+
+int aria_kfdb_info(aria_kfdb_t db, int index, long long* id, int* count) {
+    if (!db || index < 0 || index >= db->n) return ARIA_E_INVALID;
+    const int slot = (db->head + index) % db->cap;
+    if (id) *id = db->ids[(size_t)slot];
+    if (count) *count = db->counts[(size_t)slot];
+    return ARIA_OK;
+}
+
+int aria_kfdb_fetch(aria_kfdb_t db, int index, uint8_t* desc, int cap_rows, int* n_out) {
+    if (!db || index < 0 || index >= db->n || cap_rows < 0) return ARIA_E_INVALID;
+    const int slot = (db->head + index) % db->cap;
+    const int n = db->counts[(size_t)slot];
+    if (n_out) *n_out = n;
+    if (n > cap_rows) return ARIA_E_OUTPUT_TOO_SMALL;
+    ARIA_HIP(hipSetDevice(db->device));
+    if (n > 0) {
+        if (!desc) return ARIA_E_INVALID;
+        ARIA_HIP(hipMemcpy(desc, db->d_desc + (size_t)slot * db->rows * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    return ARIA_OK;
+}
+
+int aria_kfdb_scan(aria_kfdb_t db, aria_matcher_t m, const uint8_t* q, int nq, double ratio, int* good, int cap, int* n_out) {
+    if (!db || !m || nq < 0 || cap < 0 || (nq > 0 && !q)) return ARIA_E_INVALID;
+    if (db->device != m->device) return ARIA_E_INVALID;
+    if (n_out) *n_out = db->n;
+    if (db->n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
+    if (db->n == 0) return ARIA_OK;
+    if (!good) return ARIA_E_INVALID;
+    if (nq > m->max_query) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(db->device));
+    std::vector<int> phys((size_t)db->cap, 0);
+    if (nq > 0) {
+        std::memcpy(m->h_stage, q, (size_t)nq * 32);
+        ARIA_HIP(hipMemcpyAsync(m->d_q, m->h_stage, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+        // every physical slot is scanned (empty ones hold count 0); one launch for the whole database
+        int rc = aria_matcher_match_db_device(m, m->d_q, nq, db->d_desc, db->d_counts, db->cap, (int64_t)db->rows * 32, ratio, db->d_good);
+        if (rc != ARIA_OK) return rc;
+        ARIA_HIP(hipMemcpyAsync(phys.data(), db->d_good, sizeof(int) * (size_t)db->cap, hipMemcpyDeviceToHost, m->stream));
+        ARIA_HIP(hipStreamSynchronize(m->stream));
+    }
+    for (int i = 0; i < db->n; i++) good[i] = phys[(size_t)((db->head + i) % db->cap)];
     return ARIA_OK;
 }
 

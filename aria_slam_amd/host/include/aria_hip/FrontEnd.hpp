@@ -9,6 +9,7 @@
 #pragma once
 #include <functional>
 #include <memory>
+#include <optional>
 #include <vector>
 
 #include "aria_hip/compat.hpp"
@@ -20,17 +21,26 @@ struct FrontEndConfig {
     // false: query = current, train = previous (SlamPipeline sketch, H12...:601)
     // true : query = previous, train = current (what the legacy executables do, src/euroc_eval.cpp:168-169)
     bool legacy_order = false;
+    // Loop-closure step of the evaluation loop (src/euroc_eval.cpp:230-245), run when a loop detector is injected: a frame
+    // whose match list has at least keyframe_min_matches entries (the reference's pose stage needs 8 points,
+    // euroc_eval.cpp:179) becomes a keyframe -- detect() against the database first, then addKeyFrame().
+    int keyframe_min_matches = 8;
 };
 
 struct FrontEndResult {
     const core::Frame* frame = nullptr;       // the frame just extracted (owned by the FrontEnd until the next call)
     const core::Frame* previous = nullptr;    // nullptr on the first frame
     std::vector<core::Match> matches;         // empty on the first frame
+    bool is_keyframe = false;                 // the frame was handed to the loop detector
+    std::optional<core::LoopCandidate> loop;  // what ILoopDetector::detect returned for it
 };
 
 class FrontEnd {
 public:
     FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::MatcherPtr matcher, const FrontEndConfig& cfg = {});
+    // with the loop detector SlamPipeline's constructor takes third (include/pipeline/SlamPipeline.hpp:32-40)
+    FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::MatcherPtr matcher, interfaces::LoopDetectorPtr loop_detector,
+             const FrontEndConfig& cfg = {});
 
     // image_data: grayscale, row-major, width*height bytes (the extractor port's contract, IFeatureExtractor.hpp:14)
     const FrontEndResult& processFrame(const std::uint8_t* image_data, int width, int height, double timestamp);
@@ -39,10 +49,12 @@ public:
     std::uint64_t framesProcessed() const { return next_id_; }
     interfaces::IFeatureExtractor& extractor() { return *extractor_; }
     interfaces::IMatcher& matcher() { return *matcher_; }
+    interfaces::ILoopDetector* loopDetector() { return loop_detector_.get(); }
 
 private:
     interfaces::FeatureExtractorPtr extractor_;
     interfaces::MatcherPtr matcher_;
+    interfaces::LoopDetectorPtr loop_detector_;
     FrontEndConfig cfg_;
     std::unique_ptr<core::Frame> cur_, prev_;
     FrontEndResult result_;

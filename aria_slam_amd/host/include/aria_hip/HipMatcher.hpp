@@ -23,6 +23,11 @@ public:
     void match(const core::Frame& query, const core::Frame& train, std::vector<core::Match>& matches,
                float ratio_threshold = 0.75f) override;
 
+    // One batch on the device instead of the interface's default loop (IMatcher.hpp:27-37): the query is uploaded once,
+    // ONE kNN-2 launch covers every candidate. Resizes the outer vector and appends per candidate, like the default.
+    void matchMultiple(const core::Frame& query, const std::vector<core::Frame>& candidates,
+                       std::vector<std::vector<core::Match>>& all_matches, float ratio_threshold = 0.75f) override;
+
     // LoopClosureDetector::findCandidates semantics (reference src/legacy/LoopClosure.cpp:72-114) over clean-
     // architecture frames: kNN-2 of the query against every keyframe, ratio 0.7 in double, score = good/|query|,
     // keep > 0.1, best 5. Returns (index into keyframes, score).
@@ -31,6 +36,7 @@ public:
                                                           int min_frames_between);
 
     aria_matcher_s* handle() const { return m_; }
+    void reserve(int nq, int nt) { ensure(nq, nt); }       // creates / grows the C handle
 
 private:
     void ensure(int nq, int nt);

@@ -33,6 +33,7 @@ public:
 private:
     void ensure(int width, int height);
     void fill(core::Frame& frame, int width, int height, int n);
+    int refetch(int rows);
 
     aria_orb_s* h_ = nullptr;
     void* stream_;

@@ -9,12 +9,14 @@
 
 #ifdef ARIA_HIP_USE_REFERENCE_HEADERS
 #include "interfaces/IFeatureExtractor.hpp"
+#include "interfaces/ILoopDetector.hpp"
 #include "interfaces/IMatcher.hpp"
 #else
 
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <optional>
 #include <vector>
 
 namespace aria::core {
@@ -38,6 +40,31 @@ struct Frame {
 struct Match {
     int query_idx, train_idx;
     float distance;
+};
+
+// include/core/Types.hpp:103-112 (the box test of SlamPipeline::filterDynamicKeypoints, SlamPipeline.hpp:96-99)
+struct Detection {
+    float x1, y1, x2, y2;
+    float confidence;
+    int class_id;
+    bool contains(float x, float y) const { return x >= x1 && x <= x2 && y >= y1 && y <= y2; }
+};
+
+// include/core/Types.hpp:33-45: the members the loop-closure path touches (pose members are Eigen types there)
+struct KeyFrame {
+    std::uint64_t id = 0;
+    double timestamp = 0.0;
+    Frame frame;
+    alignas(16) double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
+
+// include/core/Types.hpp:114-121
+struct LoopCandidate {
+    std::uint64_t query_id = 0;
+    std::uint64_t match_id = 0;
+    double score = 0.0;
+    std::vector<Match> matches;
+    alignas(16) double relative_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
 }  // namespace aria::core
@@ -69,6 +96,19 @@ public:
     }
 };
 using MatcherPtr = std::unique_ptr<IMatcher>;
+
+// include/interfaces/ILoopDetector.hpp:11-31
+class ILoopDetector {
+public:
+    virtual ~ILoopDetector() = default;
+    virtual void addKeyFrame(const core::KeyFrame& kf) = 0;
+    virtual std::optional<core::LoopCandidate> detect(const core::KeyFrame& query) = 0;
+    virtual int getLoopCount() const = 0;
+    virtual void setMinFramesBetween(int n) = 0;
+    virtual void setMinScore(double s) = 0;
+    virtual void setMinMatches(int n) = 0;
+};
+using LoopDetectorPtr = std::unique_ptr<ILoopDetector>;
 
 }  // namespace aria::interfaces
 

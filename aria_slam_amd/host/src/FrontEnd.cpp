@@ -11,6 +11,12 @@ FrontEnd::FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::Matche
     if (!extractor_ || !matcher_) throw std::invalid_argument("FrontEnd: extractor and matcher must not be null");
 }
 
+FrontEnd::FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::MatcherPtr matcher,
+                   interfaces::LoopDetectorPtr loop_detector, const FrontEndConfig& cfg)
+    : FrontEnd(std::move(extractor), std::move(matcher), cfg) {
+    loop_detector_ = std::move(loop_detector);
+}
+
 const FrontEndResult& FrontEnd::processFrame(const std::uint8_t* image_data, int width, int height, double timestamp) {
     std::unique_ptr<core::Frame> f = std::make_unique<core::Frame>();
     f->id = next_id_++;
@@ -25,6 +31,17 @@ const FrontEndResult& FrontEnd::processFrame(const std::uint8_t* image_data, int
     if (prev_) {
         if (cfg_.legacy_order) matcher_->match(*prev_, *cur_, result_.matches, cfg_.ratio_threshold);   // euroc_eval.cpp:168-169
         else matcher_->match(*cur_, *prev_, result_.matches, cfg_.ratio_threshold);                      // H12...:601
+    }
+    result_.is_keyframe = false;
+    result_.loop.reset();
+    if (loop_detector_ && prev_ && (int)result_.matches.size() >= cfg_.keyframe_min_matches) {
+        core::KeyFrame kf;                                        // euroc_eval.cpp:230-236
+        kf.id = cur_->id;
+        kf.timestamp = cur_->timestamp;
+        kf.frame = *cur_;
+        result_.loop = loop_detector_->detect(kf);                // :238-239
+        loop_detector_->addKeyFrame(kf);                          // :247
+        result_.is_keyframe = true;
     }
     if (callback_) callback_(result_);
     return result_;

@@ -55,26 +55,61 @@ void HipMatcher::match(const core::Frame& query, const core::Frame& train, std::
     matches.insert(matches.end(), buf_.begin(), buf_.begin() + n);            // :65 push_back, never cleared
 }
 
+void HipMatcher::matchMultiple(const core::Frame& query, const std::vector<core::Frame>& candidates,
+                               std::vector<std::vector<core::Match>>& all_matches, float ratio_threshold) {
+    all_matches.resize(candidates.size());                                      // IMatcher.hpp:33
+    if (candidates.empty() || query.descriptors.empty()) return;                // every match() would return at once
+    const int nq = (int)query.numKeypoints();
+    if ((size_t)nq * 32 > query.descriptors.size()) fail("matchMultiple: descriptors shorter than numKeypoints()*32", ARIA_E_INVALID);
+    std::vector<const std::uint8_t*> ptrs(candidates.size());
+    std::vector<int> nts(candidates.size()), n_out(candidates.size());
+    int max_nt = 1;
+    for (size_t i = 0; i < candidates.size(); i++) {
+        const core::Frame& c = candidates[i];
+        nts[i] = c.descriptors.empty() ? 0 : (int)c.numKeypoints();             // empty train set: untouched (CudaMatcher.cpp:35-37)
+        if ((size_t)nts[i] * 32 > c.descriptors.size()) fail("matchMultiple: descriptors shorter than numKeypoints()*32", ARIA_E_INVALID);
+        ptrs[i] = c.descriptors.data();
+        max_nt = std::max(max_nt, nts[i]);
+    }
+    ensure(nq, max_nt);
+    buf_.resize(candidates.size() * (size_t)nq);
+    int rc = aria_matcher_match_multi(m_, query.descriptors.data(), nq, ptrs.data(), nts.data(), (int)candidates.size(),
+                                      ratio_threshold, reinterpret_cast<aria_match*>(buf_.data()), nq, n_out.data());
+    if (rc != ARIA_OK) fail("aria_matcher_match_multi", rc);
+    for (size_t i = 0; i < candidates.size(); i++)
+        all_matches[i].insert(all_matches[i].end(), buf_.begin() + i * (size_t)nq, buf_.begin() + i * (size_t)nq + n_out[i]);
+}
+
 std::vector<std::pair<int, double>> HipMatcher::findLoopCandidates(const core::Frame& query,
                                                                   const std::vector<core::Frame>& keyframes,
                                                                   int min_frames_between) {
     std::vector<std::pair<int, double>> candidates;
     if (query.descriptors.empty()) return candidates;                          // LoopClosure.cpp:75
     const int nq = (int)query.numKeypoints();
+    // the keyframes that pass the host-side filters (:81, :83) go to the device in one batch: one upload of the query,
+    // one kNN-2 launch over all of them (the reference runs one CPU knnMatch per keyframe, :87)
+    std::vector<int> which;
+    std::vector<const std::uint8_t*> ptrs;
+    std::vector<int> nts;
+    int max_nt = 1;
     for (size_t i = 0; i < keyframes.size(); i++) {
         const core::Frame& kf = keyframes[i];
         if ((long long)query.id - (long long)kf.id < (long long)min_frames_between) continue;   // :81
         if (kf.descriptors.empty()) continue;                                  // :83
-        const int nt = (int)kf.numKeypoints();
-        ensure(nq, nt);
-        std::vector<int> idx((size_t)nq * 2), dist((size_t)nq * 2);
-        int rc = aria_matcher_knn2(m_, query.descriptors.data(), nq, kf.descriptors.data(), nt, idx.data(), dist.data());
-        if (rc != ARIA_OK) fail("aria_matcher_knn2", rc);
-        int good = 0;
-        for (int q = 0; q < nq; q++)                                           // :90-95, double literal 0.7
-            if (idx[2 * q + 1] >= 0 && (double)(float)dist[2 * q] < 0.7 * (double)(float)dist[2 * q + 1]) good++;
-        const double score = (double)good / std::max(1, nq);                  // :98
-        if (score > 0.1) candidates.push_back({(int)i, score});                // :99
+        which.push_back((int)i);
+        ptrs.push_back(kf.descriptors.data());
+        nts.push_back((int)kf.numKeypoints());
+        max_nt = std::max(max_nt, nts.back());
+    }
+    if (which.empty()) return candidates;
+    ensure(nq, max_nt);
+    std::vector<int> good(which.size());
+    int rc = aria_matcher_count_good_multi(m_, query.descriptors.data(), nq, ptrs.data(), nts.data(), (int)which.size(), 0.7,
+                                           good.data());                       // :90-95, double literal 0.7
+    if (rc != ARIA_OK) fail("aria_matcher_count_good_multi", rc);
+    for (size_t k = 0; k < which.size(); k++) {
+        const double score = (double)good[k] / std::max(1, nq);               // :98
+        if (score > 0.1) candidates.push_back({which[k], score});              // :99
     }
     std::stable_sort(candidates.begin(), candidates.end(),
                      [](const auto& a, const auto& b) { return a.second > b.second; });   // :105-106

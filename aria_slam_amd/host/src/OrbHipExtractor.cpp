@@ -52,6 +52,15 @@ void OrbHipExtractor::ensure(int width, int height) {
     desc_buf_.resize((size_t)cap * 32);
 }
 
+// OpenCV keeps every keypoint that ties with the last kept one, so a frame can need more rows than the plan provides:
+// grow the buffers to what the call reported and copy the (still resident) result out again.
+int OrbHipExtractor::refetch(int rows) {
+    kp_buf_.resize((size_t)rows);
+    desc_buf_.resize((size_t)rows * 32);
+    int n = 0;
+    return aria_orb_fetch_last(h_, reinterpret_cast<aria_keypoint*>(kp_buf_.data()), desc_buf_.data(), rows, &n);
+}
+
 void OrbHipExtractor::fill(core::Frame& frame, int width, int height, int n) {
     frame.width = width;                                       // OrbCudaExtractor.cpp:109-110
     frame.height = height;
@@ -64,6 +73,7 @@ void OrbHipExtractor::extract(const std::uint8_t* image_data, int width, int hei
     int n = 0;
     int rc = aria_orb_extract(h_, image_data, width, height, width, reinterpret_cast<aria_keypoint*>(kp_buf_.data()),
                               desc_buf_.data(), (int)kp_buf_.size(), &n);
+    if (rc == ARIA_E_OUTPUT_TOO_SMALL) rc = refetch(n);            // tie storm: more keypoints than the plan's rows
     if (rc != ARIA_OK) fail("aria_orb_extract", rc);
     fill(frame, width, height, n);
 }
@@ -81,6 +91,7 @@ void OrbHipExtractor::sync() {
     if (!pending_frame_) return;                               // OrbCudaExtractor.cpp:177
     int n = 0;
     int rc = aria_orb_sync(h_, reinterpret_cast<aria_keypoint*>(kp_buf_.data()), desc_buf_.data(), (int)kp_buf_.size(), &n);
+    if (rc == ARIA_E_OUTPUT_TOO_SMALL) rc = refetch(n);
     core::Frame* f = pending_frame_;
     pending_frame_ = nullptr;                                  // :209
     if (rc != ARIA_OK) fail("aria_orb_sync", rc);

@@ -204,6 +204,33 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
  * Scoring/top-5 (LoopClosure.cpp:98-111) is host logic in the adapter. */
 int aria_matcher_match_db_device(aria_matcher_t m, const uint8_t* d_query, int nq, const uint8_t* d_db,
                          const int* d_kf_counts, int n_kf, int64_t desc_stride, double ratio, int* d_good);
+/* IMatcher::matchMultiple (include/interfaces/IMatcher.hpp:27-37) in one batch: the query is uploaded once, every
+ * candidate's descriptors go to a device staging area back to back, ONE kNN-2 launch covers all candidates, one
+ * download. Candidate c's matches are written at matches + c*cap_per_cand, its count at n_out[c]; per candidate the
+ * result equals aria_matcher_match(query, candidate c). Host buffers. */
+int aria_matcher_match_multi(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* const* train_descs,
+                             const int* nts, int n_cand, float ratio, aria_match* matches, int cap_per_cand, int* n_out);
+/* The scan of LoopClosureDetector::findCandidates (src/legacy/LoopClosure.cpp:79-96) over host-resident candidates:
+ * good[c] = number of queries whose two nearest neighbours in candidate c pass d0 < ratio*d1 in double. One launch. */
+int aria_matcher_count_good_multi(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* const* train_descs,
+                                  const int* nts, int n_cand, double ratio, int* good);
+
+/* ---- HBM-resident keyframe descriptor database: the deque of LoopClosureDetector (src/legacy/LoopClosure.cpp:24-31;
+ * docs/milestones/H14_GPU_LOOPCLOSURE_AUDIT.md designs exactly this). Fixed-capacity slots of `rows` descriptors;
+ * adding beyond `capacity` drops the oldest keyframe (pop_front, :28-30). Index i below = position in the deque,
+ * oldest first. The scan is one kernel launch over the whole database. */
+typedef struct aria_kfdb_s* aria_kfdb_t;
+int  aria_kfdb_create(int device, void* stream, int capacity, int rows, aria_kfdb_t* out);
+void aria_kfdb_destroy(aria_kfdb_t db);
+int  aria_kfdb_size(aria_kfdb_t db);
+int  aria_kfdb_add(aria_kfdb_t db, long long id, const uint8_t* desc_host, int n);
+int  aria_kfdb_add_device(aria_kfdb_t db, long long id, const uint8_t* d_desc, int n);
+int  aria_kfdb_info(aria_kfdb_t db, int index, long long* id, int* count);
+int  aria_kfdb_fetch(aria_kfdb_t db, int index, uint8_t* desc_host, int cap_rows, int* n_out);
+/* good[i] for every keyframe i (ratio test in double, LoopClosure.cpp:92); *n_out = keyframes. Host query. */
+int  aria_kfdb_scan(aria_kfdb_t db, aria_matcher_t m, const uint8_t* query_desc, int nq, double ratio, int* good, int cap,
+                    int* n_out);
+
 /* Same for the matcher: stage 0 = kNN-2 kernel, stage 1 = ratio test + ordered compaction. */
 #define ARIA_MATCHER_STAGES 2
 int aria_matcher_set_profiling(aria_matcher_t m, int enable);

@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "aria_hip/FrontEnd.hpp"
+#include "aria_hip/HipFactory.hpp"
+#include "aria_hip/HipLoopDetector.hpp"
 #include "aria_hip/HipMatcher.hpp"
 #include "aria_hip/OrbHipExtractor.hpp"
 #include "aria_orb_hip.h"
@@ -131,6 +133,9 @@ int main(int argc, char** argv) {
     std::vector<std::vector<core::Match>> all(7);
     matcher->matchMultiple(fb, cands, all, 0.75f);
     std::printf("multi %zu %zu %zu %zu\n", all.size(), all[0].size(), all[1].size(), all[2].size());
+    // the batched matchMultiple must give, per candidate, exactly what match() gives
+    std::printf("multi_hash %016llx %016llx\n", fnv(all[0].data(), all[0].size() * sizeof(core::Match)),
+                fnv(all[1].data(), all[1].size() * sizeof(core::Match)));
 
     extractor->setMaxFeatures(500);
     core::Frame f500;
@@ -144,6 +149,35 @@ int main(int argc, char** argv) {
     std::vector<core::Frame> kfs = {fa};
     auto lc = hm->findLoopCandidates(fb, kfs, 30);
     std::printf("loop %zu %.6f\n", lc.size(), lc.empty() ? 0.0 : lc[0].second);
+    // ILoopDetector over the HBM-resident database: capacity 3 -> the fourth keyframe drops the oldest (LoopClosure.cpp:28-30)
+    {
+        adapters::hip::HipLoopDetector ld(1, 0.3, 30, 4096, 3);
+        core::KeyFrame k0, k1, k2, k3, q;
+        k0.id = 0; k0.frame = fa; k1.id = 1; k1.frame = fb; k2.id = 2; k2.frame = f500; k3.id = 3; k3.frame = fa;
+        ld.addKeyFrame(k0); ld.addKeyFrame(k1); ld.addKeyFrame(k2); ld.addKeyFrame(k3);
+        q.id = 50; q.frame = fb;
+        auto cands = ld.findCandidates(q);
+        std::printf("ld_size %d oldest %llu ncand %zu\n", ld.size(), (unsigned long long)ld.keyframeId(0), cands.size());
+        for (auto& c : cands) std::printf("ld_cand %llu %.17g\n", (unsigned long long)ld.keyframeId(c.first), c.second);
+        auto loop = ld.detect(q);
+        std::printf("ld_loop %d %llu %zu %d\n", (int)loop.has_value(), loop ? (unsigned long long)loop->match_id : 0ull,
+                    loop ? loop->matches.size() : (size_t)0, ld.getLoopCount());
+        q.id = 3;                                            // nothing is min_frames_between older than this query ... except id <= 2
+        ld.setMinFramesBetween(10);
+        std::printf("ld_recent %d\n", (int)ld.detect(q).has_value());
+    }
+    // PipelineFactory's HIP mode: the three components, wired into the front end
+    {
+        factory::HipFactoryConfig fc;
+        fc.max_features = 2000;
+        fc.loop_min_frames_between = 1;
+        auto fe = factory::createHip(fc);
+        const auto& r0 = fe->processFrame(a.data(), W, H, 0.0);
+        const size_t n0 = r0.frame->numKeypoints();
+        const auto& r1 = fe->processFrame(b.data(), W, H, 0.05);
+        std::printf("factory %zu %zu %zu %d %d\n", n0, r1.frame->numKeypoints(), r1.matches.size(), (int)r1.is_keyframe,
+                    fe->loopDetector() != nullptr);
+    }
     std::printf("DONE\n");
     return 0;
 }

@@ -58,10 +58,21 @@ def test_adapters_equal_python_binding_and_reference_conventions(aria, selftest)
     assert kv["matches"] == [_fnv(mm.tobytes())]
     assert kv["empty_untouched"] == ["1"]                                  # CudaMatcher.cpp:35-37
     assert kv["multi"] == ["3", str(len(mm)), str(len(m.match(fb, fb))), "0"]   # IMatcher.hpp:33 resize + loop
+    assert kv["multi_hash"] == [_fnv(mm.tobytes()), _fnv(m.match(fb, fb).tobytes())]   # one batched launch == per-candidate match()
     e.setMaxFeatures(500)
     f5 = e.extract(a)
     assert kv["n_500"] == [str(len(f5["keypoints"])), "max", "500"]
     assert kv["kp_500"] == [_fnv(f5["keypoints"].tobytes()), "desc_500", _fnv(f5["descriptors"].tobytes())]
     assert kv["loop"][0] == "1" and float(kv["loop"][1]) > 0.1
+    # HipLoopDetector (ILoopDetector over the HBM-resident database), capacity 3 after four insertions
+    from oracle import oracle_py as O
+    blocks = [fb["descriptors"], f5["descriptors"], fa["descriptors"]]
+    ci, cs = O.loop_candidates(fb["descriptors"], 50, blocks, [1, 2, 3], 1)
+    assert kv["ld_size"] == ["3", "oldest", "1", "ncand", str(len(ci))]
+    got = [(int(t[1]), float(t[2])) for t in (l.split() for l in out.stdout.splitlines()) if t[0] == "ld_cand"]
+    assert [g[0] for g in got] == [[1, 2, 3][i] for i in ci.tolist()] and [g[1] for g in got] == cs.tolist()
+    assert kv["ld_loop"][0] == "1" and kv["ld_loop"][1] == "1" and int(kv["ld_loop"][2]) == len(m.match(fb, fb, None, 0.7)) and kv["ld_loop"][3] == "1"
+    assert kv["ld_recent"] == ["0"]
+    assert kv["factory"] == [str(len(fa["keypoints"])), str(len(fb["keypoints"])), str(len(mm)), "1", "1"]
     e.close()
     m.close()

@@ -93,10 +93,12 @@ def test_png_decoder_all_filters_and_colour_types(aria, hostlib):
         assert _decode(hostlib, bad)[0] != 0
 
 
-def _make_dataset(aria, root, n_pairs, w=320, h=240, shuffle=True):
+def _make_dataset(aria, root, n_pairs, w=320, h=240, shuffle=True, revisit=0):
     cam = os.path.join(root, "mav0", "cam0", "data")
     os.makedirs(cam, exist_ok=True)
     seq = aria.synth_sequence(40, n_pairs, w, h)
+    if revisit:                                                     # the sequence comes back to its first frames: a loop
+        seq = np.concatenate([seq, seq[:revisit]])
     t0 = 1403636579763555584
     rows = []
     for i in range(len(seq)):
@@ -160,3 +162,76 @@ def test_euroc_frontend_driver_on_synthetic_asl(aria, hostlib, tmp_path, legacy)
         e.close()
         m.close()
     assert "mean_matches" in out.stdout
+
+
+def _fnv1a(parts):
+    h = 14695981039346656037
+    for p in parts:
+        for b in np.ascontiguousarray(p).view(np.uint8).reshape(-1).tolist():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+def test_euroc_frontend_hashes_equal_the_oracle_at_euroc_size(aria, hostlib, oracle, tmp_path):
+    """BASELINE.json configs[0]: 752x480 mono, 1000 kp/frame through the euroc_eval-equivalent driver (PipelineFactory's
+    HIP mode -> FrontEnd -> C++ adapters -> C-ABI). Every frame's keypoint records, descriptor rows and match records
+    (query = current, train = previous) hash to what the ORACLE produces for the same PNG files."""
+    seq, _ = _make_dataset(aria, str(tmp_path), 5, w=752, h=480)
+    csv = os.path.join(str(tmp_path), "out.csv")
+    out = subprocess.run([os.path.join(PKG, "euroc_frontend"), str(tmp_path), "1000", "--csv", csv], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l.split(",") for l in open(csv).read().strip().split("\n")[1:]]
+    assert len(rows) == len(seq)
+    p = oracle.default_params(1000)
+    prev = None
+    for i, img in enumerate(seq):
+        k, d = oracle.orb_extract(img, p)
+        m = oracle.match_ratio(d, prev, 0.75) if prev is not None else np.zeros(0, oracle.MATCH_DTYPE)
+        assert int(rows[i][2]) == len(k) and int(rows[i][3]) == len(m), i
+        assert int(rows[i][4]) == _fnv1a([k, d, m]), i
+        prev = d
+
+
+@pytest.mark.gpu
+def test_euroc_frontend_loop_closure_step(aria, hostlib, oracle, tmp_path):
+    """--loop: keyframe insertion and the loop query of src/euroc_eval.cpp:103, 230-247 over ILoopDetector, database in
+    HBM. The sequence returns to its first frames after 460 frames (about half of them become keyframes); the detector (min_frames_between 200, min_score 0.4,
+    min_matches 50) must report exactly the loops the oracle's restatement of LoopClosureDetector::findCandidates +
+    the same acceptance rule gives."""
+    n_pairs, revisit = 230, 6
+    seq, _ = _make_dataset(aria, str(tmp_path), n_pairs, w=320, h=240, revisit=revisit)
+    csv = os.path.join(str(tmp_path), "out.csv")
+    out = subprocess.run([os.path.join(PKG, "euroc_frontend"), str(tmp_path), "500", "--csv", csv, "--loop"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l.split(",") for l in open(csv).read().strip().split("\n")[1:]]
+    assert len(rows) == len(seq) == 2 * n_pairs + revisit
+    p = oracle.default_params(500)
+    descs, kf = [], []                       # kf: (frame id, descriptors)
+    want_loops = {}
+    for i, img in enumerate(seq):
+        k, d = oracle.orb_extract(img, p)
+        nm = len(oracle.match_ratio(d, descs[-1], 0.75)) if descs else 0
+        descs.append(d)
+        is_kf = i > 0 and nm >= 8
+        assert int(rows[i][5]) == int(is_kf), i
+        if not is_kf:
+            continue
+        if len(kf) >= 200:                                           # LoopClosure.cpp:34-36
+            ci, cs = oracle.loop_candidates(d, i, [x[1] for x in kf], [x[0] for x in kf], 200)
+            for idx, score in zip(ci.tolist(), cs.tolist()):
+                if score < 0.4:
+                    continue
+                if len(oracle.match_ratio(d, kf[idx][1], 0.7)) < 50:
+                    continue
+                want_loops[i] = (kf[idx][0], score)
+                break
+        kf.append((i, d))
+        kf = kf[-500:]
+    got_loops = {i: (int(r[6]), float(r[7])) for i, r in enumerate(rows) if int(r[6]) >= 0}
+    assert want_loops, "the test sequence must contain a loop"
+    assert set(got_loops) == set(want_loops)
+    for i in want_loops:
+        assert got_loops[i][0] == want_loops[i][0] and abs(got_loops[i][1] - want_loops[i][1]) < 1e-6
