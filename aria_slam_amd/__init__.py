@@ -7,7 +7,7 @@ compute of its own and no CPU fallback: if the HIP library is missing or no GPU 
 """
 from ._lib import (KP_DTYPE, MATCH_DTYPE, AriaError, abi_version, algorithmic_bytes, build_library, level_info,
                    library_path, load_library, resize_table, status_string, synth_frame_pair, synth_sequence)
-from .frontend import HipMatcher, OrbHipExtractor
+from .frontend import HipMatcher, OrbHipExtractor, flag_keypoints_device
 
 __all__ = ["KP_DTYPE", "MATCH_DTYPE", "AriaError", "abi_version", "build_library", "library_path", "load_library",
-           "status_string", "level_info", "resize_table", "algorithmic_bytes", "synth_frame_pair", "synth_sequence", "HipMatcher", "OrbHipExtractor"]
+           "status_string", "level_info", "resize_table", "algorithmic_bytes", "synth_frame_pair", "synth_sequence", "HipMatcher", "OrbHipExtractor", "flag_keypoints_device"]

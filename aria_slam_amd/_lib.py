@@ -28,7 +28,7 @@ EXPORTS = [
     "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
     "aria_matcher_knn2", "aria_matcher_match_batch_device", "aria_matcher_match_db_device",
     "aria_matcher_stream", "aria_matcher_sync", "aria_synth_frame_pair", "aria_synth_sequence",
-    "aria_matcher_match_multi", "aria_matcher_count_good_multi", "aria_kfdb_create", "aria_kfdb_destroy", "aria_kfdb_size",
+    "aria_flag_keypoints_device", "aria_matcher_match_batch_filtered_device", "aria_matcher_match_multi", "aria_matcher_count_good_multi", "aria_kfdb_create", "aria_kfdb_destroy", "aria_kfdb_size",
     "aria_kfdb_add", "aria_kfdb_add_device", "aria_kfdb_info", "aria_kfdb_fetch", "aria_kfdb_scan",
 ]
 
@@ -141,6 +141,11 @@ def load_library():
                                                   C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
     L.aria_matcher_match_db_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_int64, C.c_double, C.c_void_p]
+    L.aria_flag_keypoints_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_void_p]
+    L.aria_matcher_match_batch_filtered_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                           C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                           C.c_void_p, C.c_int, C.c_void_p]
     L.aria_orb_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.aria_orb_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64)]

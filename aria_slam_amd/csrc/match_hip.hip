@@ -133,11 +133,18 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
 
 // CudaMatcher.cpp:59-67: fp32 Lowe test, matches appended in query order. One workgroup per pair; the ordered
 // compaction uses wave ballots + popcount prefixes.
+// qflags / tflags (optional): per-keypoint "lies in a dynamic object" flags of the query / train frame of every pair
+// (k_flag_keypoints); a ratio-test survivor with a flagged endpoint is dropped and counted (src/main.cpp:164-175).
 __global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__ keys, const int* __restrict__ nq_arr,
                                                        int nq_fixed, int maxq, float ratio,
                                                        aria_match* __restrict__ out, int* __restrict__ nout, int cap,
-                                                       int* __restrict__ err) {
+                                                       int* __restrict__ err, const uint8_t* __restrict__ qflags = nullptr,
+                                                       const uint8_t* __restrict__ tflags = nullptr, int64_t flag_stride = 0,
+                                                       int* __restrict__ nfiltered = nullptr) {
     __shared__ int s_w[4];
+    __shared__ int s_f;
+    if (threadIdx.x == 0) s_f = 0;
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pair = blockIdx.x;
     const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
@@ -152,6 +159,10 @@ __global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__
             k = kk[qi];
             if (ratio == 0.0f) ok = k.x != 0xFFFFFFFFu;   // IMatcher.hpp:18 "0.0 = disabled"
             else ok = k.y != 0xFFFFFFFFu && (float)(k.x >> 16) < ratio * (float)(k.y >> 16);
+            if (ok && qflags && (qflags[(int64_t)pair * flag_stride + qi] | tflags[(int64_t)pair * flag_stride + (k.x & 0xFFFFu)])) {
+                ok = false;
+                atomicAdd(&s_f, 1);
+            }
         }
         const unsigned long long m = __ballot(ok);
         if (lane == 0) s_w[wv] = __popcll(m);
@@ -174,7 +185,39 @@ __global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__
         base += tot;
         __syncthreads();
     }
-    if (tid == 0) nout[pair] = min(base, cap);
+    if (tid == 0) {
+        nout[pair] = min(base, cap);
+        if (nfiltered) nfiltered[pair] = s_f;
+    }
+}
+
+// src/main.cpp:42-50 isInDynamicObject for every keypoint of every frame: flags[f][i] = 1 when keypoint i lies in one of
+// frame f's boxes (x1, y1, x2, y2). mode 0: cv::Rect::contains of the point rounded to integers (half to even), half-open;
+// mode 1: core::Detection::contains (include/core/Types.hpp:109-111), closed float intervals.
+__global__ __launch_bounds__(256) void k_flag_keypoints(const aria_keypoint* __restrict__ kps, const int* __restrict__ counts,
+                                                        int kp_cap, const float4* __restrict__ boxes, const int* __restrict__ nboxes,
+                                                        int box_cap, int mode, uint8_t* __restrict__ flags) {
+    __shared__ float4 s_box[64];
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int nb = min(nboxes[f], box_cap), n = min(counts[f], kp_cap);
+    bool hit = false;
+    float x = 0.f, y = 0.f;
+    if (i < n) { x = kps[(int64_t)f * kp_cap + i].x; y = kps[(int64_t)f * kp_cap + i].y; }
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        __syncthreads();
+        if (threadIdx.x < 64 && b0 + (int)threadIdx.x < nb) s_box[threadIdx.x] = boxes[(int64_t)f * box_cap + b0 + threadIdx.x];
+        __syncthreads();
+        for (int b = 0; b < min(64, nb - b0); b++) {
+            const float4 r = s_box[b];
+            if (mode == 0) {
+                const int px = __float2int_rn(x), py = __float2int_rn(y);
+                hit |= (int)r.x <= px && px < (int)r.z && (int)r.y <= py && py < (int)r.w;
+            } else {
+                hit |= x >= r.x && x <= r.z && y >= r.y && y <= r.w;
+            }
+        }
+    }
+    if (i < kp_cap) flags[(int64_t)f * kp_cap + i] = (i < n && hit) ? 1 : 0;
 }
 
 __global__ void k_unpack_knn(const uint2* __restrict__ keys, int nq, int* __restrict__ idx, int* __restrict__ dist) {
@@ -477,6 +520,38 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
                        d_matches, d_nmatches, match_cap, m->d_err);
     if (p1) { hipEventRecord(ev.e[3], m->stream); hipStreamSynchronize(m->stream); }
     if (m->prof_enabled) m->prof_pending.push_back(ev);
+    ARIA_HIP(hipGetLastError());
+    return ARIA_OK;
+}
+
+int aria_flag_keypoints_device(void* stream, const aria_keypoint* d_kps, const int* d_counts, int n_frames, int kp_cap,
+                               const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, uint8_t* d_flags) {
+    if (!d_kps || !d_counts || !d_boxes || !d_nboxes || !d_flags || n_frames < 0 || kp_cap < 1 || box_cap < 1 || (mode != 0 && mode != 1))
+        return ARIA_E_INVALID;
+    if (n_frames == 0) return ARIA_OK;
+    hipLaunchKernelGGL(k_flag_keypoints, dim3((unsigned)((kp_cap + 255) / 256), (unsigned)n_frames), dim3(256), 0, (hipStream_t)stream,
+                       d_kps, d_counts, kp_cap, reinterpret_cast<const float4*>(d_boxes), d_nboxes, box_cap, mode, d_flags);
+    ARIA_HIP(hipGetLastError());
+    return ARIA_OK;
+}
+
+int aria_matcher_match_batch_filtered_device(aria_matcher_t m, const uint8_t* d_query, const int* d_nq, const uint8_t* d_train,
+                                             const int* d_nt, int n_pairs, int64_t desc_stride, float ratio,
+                                             const uint8_t* d_qflags, const uint8_t* d_tflags, int64_t flag_stride,
+                                             aria_match* d_matches, int* d_nmatches, int match_cap, int* d_nfiltered) {
+    if (!m || !d_query || !d_nq || !d_train || !d_nt || !d_matches || !d_nmatches || !d_qflags || !d_tflags || n_pairs < 0 ||
+        match_cap < 1 || desc_stride < 32 || (desc_stride & 31) || flag_stride < desc_stride / 32)
+        return ARIA_E_INVALID;
+    if (n_pairs == 0) return ARIA_OK;
+    const int64_t maxq = desc_stride / 32;
+    if (maxq > 65535) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(m->device));
+    int rc = ensure_keys(m, (size_t)n_pairs * (size_t)maxq);
+    if (rc != ARIA_OK) return rc;
+    launch_knn2(m, 0, (int)maxq, n_pairs, d_query, d_nq, 0, d_train, d_nt, 0, desc_stride, desc_stride, m->d_keys, (int)maxq,
+                0.0, nullptr, (int)maxq);
+    hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
+                       d_matches, d_nmatches, match_cap, m->d_err, d_qflags, d_tflags, flag_stride, d_nfiltered);
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
 }

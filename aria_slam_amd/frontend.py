@@ -248,6 +248,14 @@ class HipMatcher:
                                                       n_pairs, desc_stride, C.c_float(ratio), _ptr(d_matches),
                                                       _ptr(d_nmatches), match_cap), "aria_matcher_match_batch_device")
 
+    def match_batch_filtered_device(self, d_query, d_nq, d_train, d_nt, n_pairs, desc_stride, ratio, d_qflags, d_tflags,
+                                    flag_stride, d_matches, d_nmatches, match_cap, d_nfiltered):
+        """main.cpp:164-175 on the device: ratio-test survivors with an endpoint flagged by flag_keypoints_device are dropped."""
+        check(self._L.aria_matcher_match_batch_filtered_device(
+            self._h, _ptr(d_query), _ptr(d_nq), _ptr(d_train), _ptr(d_nt), n_pairs, desc_stride, ratio,
+            _ptr(d_qflags), _ptr(d_tflags), flag_stride, _ptr(d_matches), _ptr(d_nmatches), match_cap,
+            _ptr(d_nfiltered)), "aria_matcher_match_batch_filtered_device")
+
     def match_db_device(self, d_query, nq, d_db, d_kf_counts, n_kf, desc_stride, ratio, d_good):
         check(self._L.aria_matcher_match_db_device(self._h, _ptr(d_query), nq, _ptr(d_db), _ptr(d_kf_counts), n_kf,
                                                    desc_stride, C.c_double(ratio), _ptr(d_good)),
@@ -274,3 +282,10 @@ class HipMatcher:
     @property
     def stream(self):
         return self._L.aria_matcher_stream(self._h)
+
+
+def flag_keypoints_device(stream, d_keypoints, d_counts, n_frames, kp_cap, d_boxes, d_nboxes, box_cap, mode, d_flags):
+    """main.cpp:42-50 for every keypoint of every frame (boxes are an input; mode 0 legacy cv::Rect test, 1 Detection::contains)."""
+    L = _lib.load_library()
+    check(L.aria_flag_keypoints_device(stream, _ptr(d_keypoints), _ptr(d_counts), n_frames, kp_cap, _ptr(d_boxes),
+                                       _ptr(d_nboxes), box_cap, mode, _ptr(d_flags)), "aria_flag_keypoints_device")

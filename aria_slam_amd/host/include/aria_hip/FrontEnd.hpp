@@ -25,12 +25,20 @@ struct FrontEndConfig {
     // whose match list has at least keyframe_min_matches entries (the reference's pose stage needs 8 points,
     // euroc_eval.cpp:179) becomes a keyframe -- detect() against the database first, then addKeyFrame().
     int keyframe_min_matches = 8;
+    // PipelineConfig::filter_dynamic_objects (include/pipeline/SlamPipeline.hpp:20): matches with an endpoint inside a
+    // detection of a dynamic class are dropped, as the legacy executable does (src/main.cpp:29-50, 164-175). The detector is
+    // not part of this repository: its boxes for the current frame arrive through FrontEnd::setDetections().
+    bool filter_dynamic_objects = true;
 };
+
+// COCO ids of src/main.cpp:29-40: person, bicycle, car, motorcycle, bus, train, truck, bird, cat, dog
+bool isDynamicClass(int class_id);
 
 struct FrontEndResult {
     const core::Frame* frame = nullptr;       // the frame just extracted (owned by the FrontEnd until the next call)
     const core::Frame* previous = nullptr;    // nullptr on the first frame
     std::vector<core::Match> matches;         // empty on the first frame
+    int filtered_count = 0;                   // matches dropped by the dynamic-object filter (main.cpp:172)
     bool is_keyframe = false;                 // the frame was handed to the loop detector
     std::optional<core::LoopCandidate> loop;  // what ILoopDetector::detect returned for it
 };
@@ -45,6 +53,9 @@ public:
     // image_data: grayscale, row-major, width*height bytes (the extractor port's contract, IFeatureExtractor.hpp:14)
     const FrontEndResult& processFrame(const std::uint8_t* image_data, int width, int height, double timestamp);
 
+    // Detections of the NEXT frame to be processed (the reference runs YOLO beside ORB on the same image, main.cpp:132-150);
+    // consumed by that processFrame call.
+    void setDetections(std::vector<core::Detection> detections) { detections_ = std::move(detections); }
     void setCallback(std::function<void(const FrontEndResult&)> cb) { callback_ = std::move(cb); }
     std::uint64_t framesProcessed() const { return next_id_; }
     interfaces::IFeatureExtractor& extractor() { return *extractor_; }
@@ -56,6 +67,7 @@ private:
     interfaces::MatcherPtr matcher_;
     interfaces::LoopDetectorPtr loop_detector_;
     FrontEndConfig cfg_;
+    std::vector<core::Detection> detections_;
     std::unique_ptr<core::Frame> cur_, prev_;
     FrontEndResult result_;
     std::function<void(const FrontEndResult&)> callback_;

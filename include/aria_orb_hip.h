@@ -197,6 +197,24 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
                             const uint8_t* d_train, const int* d_nt, int n_pairs, int64_t desc_stride,
                             float ratio, aria_match* d_matches, int* d_nmatches, int match_cap);
 
+/* ---- dynamic-object filter: src/main.cpp:42-50 isInDynamicObject + :164-175, the hook
+ * SlamPipeline::filterDynamicKeypoints was declared for (include/pipeline/SlamPipeline.hpp:96-99). The detector is out of
+ * scope; its boxes are an input (the caller passes the boxes of dynamic classes, main.cpp:29-40). Step 1, between describe
+ * and match: flags[f*kp_cap + i] = 1 when keypoint i of frame f lies in one of frame f's boxes (frame f's boxes at
+ * d_boxes + f*box_cap, d_nboxes[f] of them). mode 0 = the legacy test, cv::Rect::contains of the keypoint rounded to an
+ * integer point (half to even): x1 <= round(x) < x2, y1 <= round(y) < y2; mode 1 = core::Detection::contains
+ * (include/core/Types.hpp:109-111): closed float intervals. Step 2: the batched matcher drops every ratio-test survivor
+ * with a flagged endpoint and counts them (main.cpp's filtered_count) -- kNN-2 itself still sees every keypoint, as in the
+ * reference. flag_stride = flags per frame block (>= desc_stride / 32); pair p's query / train flags at
+ * d_qflags / d_tflags + p*flag_stride. */
+typedef struct { float x1, y1, x2, y2; } aria_box;
+int aria_flag_keypoints_device(void* stream, const aria_keypoint* d_keypoints, const int* d_counts, int n_frames, int kp_cap,
+                               const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, uint8_t* d_flags);
+int aria_matcher_match_batch_filtered_device(aria_matcher_t m, const uint8_t* d_query, const int* d_nq, const uint8_t* d_train,
+                                             const int* d_nt, int n_pairs, int64_t desc_stride, float ratio,
+                                             const uint8_t* d_qflags, const uint8_t* d_tflags, int64_t flag_stride,
+                                             aria_match* d_matches, int* d_nmatches, int match_cap, int* d_nfiltered);
+
 /* Loop-closure candidate scan, the semantic behind IMatcher::matchMultiple (IMatcher.hpp:27-37) as the
  * legacy code uses it (src/legacy/LoopClosure.cpp:72-114): one query descriptor set against n_kf keyframe
  * blocks resident in HBM (block k at d_db + k*desc_stride bytes, d_kf_counts[k] rows). For every keyframe:

@@ -263,3 +263,17 @@ def loop_candidates(q, query_id, db_blocks, kf_ids, min_frames_between):
                                   ids.ctypes.data_as(C.POINTER(C.c_int64)), len(db_blocks), min_frames_between,
                                   _i32(ci), cs.ctypes.data_as(C.POINTER(C.c_double)))
     return ci[:n].copy(), cs[:n].copy()
+
+
+def filter_dynamic_matches(kps_q, kps_t, matches, boxes, mode=0):
+    """src/main.cpp:42-50, 164-175 (mode 0) / core::Detection::contains (mode 1). Returns (kept matches, filtered count)."""
+    kq = np.ascontiguousarray(kps_q)
+    kt = np.ascontiguousarray(kps_t)
+    m = np.ascontiguousarray(matches)
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+    out = np.zeros(len(m), MATCH_DTYPE)
+    filt = C.c_int()
+    n = lib().orc_filter_dynamic_matches(kq.ctypes.data_as(C.c_void_p), kt.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                         len(m), b.ctypes.data_as(C.POINTER(C.c_float)), len(b), mode,
+                                         out.ctypes.data_as(C.c_void_p), C.byref(filt))
+    return out[:n].copy(), filt.value

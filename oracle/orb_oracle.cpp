@@ -623,4 +623,42 @@ int orc_loop_candidates(const uint8_t* q, int nq, int64_t query_id,
     return (int)cands.size();
 }
 
+/* ref src/main.cpp:42-50 isInDynamicObject + :164-175: a ratio-test survivor is dropped when either endpoint lies in a box
+ * of a dynamic class (the caller passes only those boxes). mode 0 = the legacy executable's test, cv::Rect::contains of the
+ * keypoint converted to an integer point (cv::Point_<int>(Point2f) rounds half to even): x1 <= cvRound(x) < x2, same for y;
+ * mode 1 = core::Detection::contains (include/core/Types.hpp:109-111): closed float intervals. boxes = (x1, y1, x2, y2).
+ * kps are 24-byte KeyPoint records (x, y first). Returns the number kept (written to out, order preserved); *filtered =
+ * main.cpp's filtered_count. */
+static bool orc_in_box(float x, float y, const float* boxes, int nb, int mode) {
+    for (int b = 0; b < nb; b++) {
+        const float* r = boxes + 4 * b;
+        if (mode == 0) {
+            const int px = (int)std::nearbyint(x), py = (int)std::nearbyint(y);
+            if ((int)r[0] <= px && px < (int)r[2] && (int)r[1] <= py && py < (int)r[3]) return true;
+        } else if (x >= r[0] && x <= r[2] && y >= r[1] && y <= r[3]) {
+            return true;
+        }
+    }
+    return false;
+}
+int orc_filter_dynamic_matches(const void* kps_q, const void* kps_t, const void* matches, int n, const float* boxes, int nb,
+                               int mode, void* out, int* filtered) {
+    const float* kq = static_cast<const float*>(kps_q);
+    const float* kt = static_cast<const float*>(kps_t);
+    const int* m = static_cast<const int*>(matches);
+    int* o = static_cast<int*>(out);
+    int kept = 0, dropped = 0;
+    for (int i = 0; i < n; i++) {
+        const int qi = m[3 * i], ti = m[3 * i + 1];
+        if (orc_in_box(kq[6 * qi], kq[6 * qi + 1], boxes, nb, mode) || orc_in_box(kt[6 * ti], kt[6 * ti + 1], boxes, nb, mode)) {
+            dropped++;
+        } else {
+            o[3 * kept] = m[3 * i]; o[3 * kept + 1] = m[3 * i + 1]; o[3 * kept + 2] = m[3 * i + 2];
+            kept++;
+        }
+    }
+    if (filtered) *filtered = dropped;
+    return kept;
+}
+
 }  // extern "C"

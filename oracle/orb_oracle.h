@@ -120,6 +120,8 @@ int  orc_match_ratio(const uint8_t* q, int nq, const uint8_t* t, int nt, float r
 /* LoopClosure.cpp:86-98 good-match count with the double-precision ratio literal (0.7).                  */
 int  orc_count_good_matches_f64(const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio);
 /* LoopClosure.cpp:72-114 findCandidates over a keyframe DB laid out as concatenated descriptor blocks.   */
+int  orc_filter_dynamic_matches(const void* kps_q, const void* kps_t, const void* matches, int n, const float* boxes, int nb,
+                                int mode, void* out, int* filtered);
 int  orc_loop_candidates(const uint8_t* q, int nq, int64_t query_id,
                          const uint8_t* db, const int* kf_counts, const int64_t* kf_ids, int n_kf,
                          int min_frames_between, int* cand_idx /*[5]*/, double* cand_score /*[5]*/);

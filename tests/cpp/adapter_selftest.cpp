@@ -73,6 +73,15 @@ static int frontend_mock_test() {
         ok &= r1.matches[0].distance == (float)(130 ^ 128);
         fe.processFrame(img.data(), 640, 480, 0.1);
         ok &= cb == 3 && fe.framesProcessed() == 3 && mtp->calls.size() == 2;
+        // dynamic-object filter (main.cpp:42-50, 164-175): the mock keypoints sit at (image[0], 2); a "person" box around
+        // them drops the match, a "chair" (class 56) box does not, and detections are consumed by one frame
+        fe.setDetections({core::Detection{100.f, 0.f, 200.f, 10.f, 0.9f, 56}});
+        ok &= fe.processFrame(img.data(), 640, 480, 0.15).matches.size() == 1;
+        fe.setDetections({core::Detection{100.f, 0.f, 200.f, 10.f, 0.9f, 0}});
+        const auto& r4 = fe.processFrame(img.data(), 640, 480, 0.2);
+        ok &= r4.matches.empty() && r4.filtered_count == 1;
+        ok &= fe.processFrame(img.data(), 640, 480, 0.25).matches.size() == 1;
+        ok &= pipeline::isDynamicClass(16) && !pipeline::isDynamicClass(4);
     }
     std::printf("%s frontend_mock\n", ok ? "OK" : "FAIL");
     return ok ? 0 : 1;

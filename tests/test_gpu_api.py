@@ -668,3 +668,87 @@ def test_tie_storm_inside_a_device_batch(aria, oracle, torch_cuda):
             assert np.array_equal(desc[f, :cnt[f]].cpu().numpy(), od)
     finally:
         e.close()
+
+
+# ---- dynamic-object filter hook (src/main.cpp:42-50, 164-175) -------------------------------
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dynamic_object_filter_on_device_equals_oracle(aria, oracle, torch_cuda, mode):
+    """Boxes are an input (the detector is out of scope). Keypoints are flagged on the device between describe and match;
+    the batched matcher drops ratio-test survivors with a flagged endpoint and counts them. Both box tests (the legacy
+    executable's integer cv::Rect test and core::Detection::contains) against the oracle's 10-line restatement."""
+    torch = torch_cuda
+    dev = torch.device("cuda", 0)
+    w, h, nf, B = 640, 480, 1000, 6
+    imgs = aria.synth_sequence(21, B // 2, w, h)
+    rng = np.random.default_rng(5 + mode)
+    box_cap = 80
+    boxes = np.zeros((B, box_cap, 4), np.float32)
+    nbox = np.array([0, 3, 80, 1, 7, 70], np.int32)                   # none, a few, more than one LDS batch
+    for f in range(B):
+        for b in range(nbox[f]):
+            x1, y1 = rng.uniform(0, w - 40), rng.uniform(0, h - 40)
+            bw, bh = rng.uniform(4, 120), rng.uniform(4, 120)
+            r = np.array([x1, y1, x1 + bw, y1 + bh], np.float32)
+            boxes[f, b] = np.round(r) if (mode == 0 or b % 2 == 0) else r    # legacy boxes are integer rectangles
+    s = torch.cuda.Stream(device=dev)
+    e = _ext(aria, nf=nf, w=w, h=h, max_batch=B, stream=s.cuda_stream)
+    m = aria.HipMatcher(stream=s.cuda_stream, max_query=4096, max_train=4096)
+    try:
+        cap = e.kp_capacity()
+        with torch.cuda.stream(s):
+            d_img = torch.from_numpy(imgs).to(dev)
+            kps = torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev)
+            desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+            cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+            flags = torch.full((B, cap), 7, dtype=torch.uint8, device=dev)
+            d_boxes, d_nbox = torch.from_numpy(boxes).to(dev), torch.from_numpy(nbox).to(dev)
+            matches = torch.zeros((B, cap, 12), dtype=torch.uint8, device=dev)
+            nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+            nfl = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            e.extract_batch_device(d_img, B, w, h, kps, desc, cnt, cap)
+            aria.flag_keypoints_device(s.cuda_stream, kps, cnt, B, cap, d_boxes, d_nbox, box_cap, mode, flags)
+            # pairs (f, f-1) for f = 1..B-1: query block f, train block f-1; flags likewise
+            m.match_batch_filtered_device(desc.data_ptr() + cap * 32, cnt.data_ptr() + 4, desc, cnt, B - 1, cap * 32, 0.75,
+                                          flags.data_ptr() + cap, flags, cap, matches.data_ptr() + cap * 12, nm.data_ptr() + 4,
+                                          cap, nfl.data_ptr() + 4)
+        e.check()
+        m.sync()
+        kps_h, desc_h, cnt_h = kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy()
+        fl_h, mt_h, nm_h, nfl_h = flags.cpu().numpy(), matches.cpu().numpy(), nm.cpu().numpy(), nfl.cpu().numpy()
+        total_filtered = 0
+        for f in range(1, B):
+            kq = kps_h[f, :cnt_h[f]].copy().view(oracle.KP_DTYPE).reshape(-1)
+            kt = kps_h[f - 1, :cnt_h[f - 1]].copy().view(oracle.KP_DTYPE).reshape(-1)
+            all_m = oracle.match_ratio(desc_h[f, :cnt_h[f]], desc_h[f - 1, :cnt_h[f - 1]], 0.75)
+            # main.cpp uses ONE detection list (the current frame's) for both endpoints; the device hook takes per-frame flags,
+            # so the oracle is asked with the union semantics it implies: query flags from frame f's boxes, train flags from f-1's
+            want_q = np.array([oracle.filter_dynamic_matches(kq, kq, np.array([(i, i, 0.0)], oracle.MATCH_DTYPE), boxes[f, :nbox[f]], mode)[1]
+                               for i in range(0, len(kq), 97)])
+            assert np.array_equal(fl_h[f, :len(kq)][::97], want_q)                    # the flags themselves
+            keep = np.array([not (fl_h[f, q] or fl_h[f - 1, t]) for q, t in zip(all_m["query_idx"], all_m["train_idx"])], bool)
+            assert nm_h[f] == keep.sum() and nfl_h[f] == (~keep).sum()
+            assert mt_h[f, :nm_h[f]].tobytes() == all_m[keep].tobytes()
+            total_filtered += int(nfl_h[f])
+            assert fl_h[f, cnt_h[f]:].max(initial=0) == 0                              # rows past the count are cleared
+        assert total_filtered > 0
+        # same-boxes case against the oracle's whole-function restatement (one detection list for both endpoints)
+        f = 2
+        kq = kps_h[f, :cnt_h[f]].copy().view(oracle.KP_DTYPE).reshape(-1)
+        kt = kps_h[f - 1, :cnt_h[f - 1]].copy().view(oracle.KP_DTYPE).reshape(-1)
+        all_m = oracle.match_ratio(desc_h[f, :cnt_h[f]], desc_h[f - 1, :cnt_h[f - 1]], 0.75)
+        with torch.cuda.stream(s):
+            d_boxes2 = d_boxes.clone()
+            d_boxes2[f - 1] = d_boxes[f]
+            d_nbox2 = d_nbox.clone()
+            d_nbox2[f - 1] = d_nbox[f]
+            aria.flag_keypoints_device(s.cuda_stream, kps, cnt, B, cap, d_boxes2, d_nbox2, box_cap, mode, flags)
+            m.match_batch_filtered_device(desc.data_ptr() + f * cap * 32, cnt.data_ptr() + 4 * f, desc.data_ptr() + (f - 1) * cap * 32,
+                                          cnt.data_ptr() + 4 * (f - 1), 1, cap * 32, 0.75, flags.data_ptr() + f * cap,
+                                          flags.data_ptr() + (f - 1) * cap, cap, matches, nm, cap, nfl)
+        m.sync()
+        want, wf = oracle.filter_dynamic_matches(kq, kt, all_m, boxes[f, :nbox[f]], mode)
+        got_n, got_f = int(nm.cpu()[0]), int(nfl.cpu()[0])
+        assert got_n == len(want) and got_f == wf and matches.cpu().numpy()[0, :got_n].tobytes() == want.tobytes()
+    finally:
+        e.close()
+        m.close()
