@@ -34,8 +34,8 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line) 
 // deferred error bits written by kernels
 enum : int {
     ERRBIT_CAND_OVERFLOW = 1,   // FAST candidate list of some (frame, level) exceeded cand_cap
-    ERRBIT_SORT_OVERFLOW = 2,   // tie-storm fallback: key arena / work list exhausted (more tied levels in one pass than provisioned)
-    ERRBIT_SEL_OVERFLOW = 4,    // tie-storm fallback: keypoint arena / work list exhausted
+    ERRBIT_SORT_OVERFLOW = 2,   // tie-storm fallback: key arena exhausted (more tied levels in one pass than provisioned)
+    ERRBIT_SEL_OVERFLOW = 4,    // tie-storm fallback: keypoint arena exhausted
     ERRBIT_KPCAP = 8,           // caller's kp_cap smaller than a frame's result
     ERRBIT_MATCHCAP = 16        // caller's match_cap smaller than a pair's result
 };

@@ -1,5 +1,6 @@
-// k_fast_blur_band: FAST-9/16 + NMS + 7x7 Gaussian for one horizontal band (16 rows x full level width) of one
-// pyramid level of one frame per workgroup.  SURVEY.md rows a6.2 (FAST), a6.3 (border filter), a6.7 (blur).
+// k_fast_blur_band: FAST-9/16 + NMS + 7x7 Gaussian + the bilinear step to the next pyramid level for one horizontal band
+// (13 output rows, 21 staged, x full level width) of one pyramid level of one frame per workgroup.
+// SURVEY.md rows a6.1 (pyramid), a6.2 (FAST), a6.3 (border filter), a6.7 (blur).
 //
 // Why this shape (MI355X):
 //  * one lane owns a 4-pixel column strip and walks DOWN the band with a 7-row window in registers, so every staged
@@ -9,11 +10,12 @@
 //  * the horizontal 7-tap pass is two v_dot4_u32_u8 per pixel on byte-shifted dwords (v_alignbyte_b32); the
 //    vertical pass is 7 integer MADs on the register window;
 //  * FAST is split: a 4-point compass reject in packed-16 arithmetic on every pixel (a 9-arc always contains one of
-//    each antipodal compass pair), survivors (~8 % of pixels) are appended to an LDS queue and scored DENSELY
+//    each antipodal compass pair), survivors (3-30 % of pixels, by level) are appended to an LDS queue and scored DENSELY
 //    afterwards (all lanes busy) with the (d, -d) packed min-tree -- score >= threshold <=> FAST-9 corner;
 //  * 3x3 strict-max NMS runs only over scored corners, candidates leave through a wave-aggregated append
 //    (ballot + popcount prefix, one global atomic per wave).
-// Integer/byte work only: no MFMA. Results are bit-identical to the tile kernel it replaces (tests/test_gpu_*).
+// Integer/byte work only: no MFMA here (band_mfma.hip is the variant with the blur on the matrix cores). Results are
+// bit-identical to the tile kernel it replaced and to that variant (tests/test_gpu_variants.py).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -118,12 +120,22 @@ __device__ __forceinline__ int fast_score_pk(const uint8_t* c, int pitch) {
 template <int TIE_EVEN, int NB1>
 __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                         uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
-                                                        int* __restrict__ cand_cnt, int* __restrict__ err, int l,
-                                                        int nb, int qcap, int ablate, unsigned long long* __restrict__ stamps,
+                                                        int* __restrict__ cand_cnt, int* __restrict__ err, int l_arg,
+                                                        int nb, int qcap_arg, int ablate, unsigned long long* __restrict__ stamps,
                                                         int* __restrict__ slow_blocks, const uint32_t* __restrict__ tab,
-                                                        uint8_t* __restrict__ raw_next) {
+                                                        uint8_t* __restrict__ raw_next, BandAll ba) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_qn, s_ovf;
+    // l_arg >= 0: this launch is level l_arg, blockIdx.x = strip. l_arg < 0 (single-frame latency schedule): ONE launch
+    // covers every level -- blockIdx.x runs over the strips of all levels (ba.first = prefix sums), one strip per workgroup
+    int l = l_arg, strip = blockIdx.x, qcap = qcap_arg;
+    if (l_arg < 0) {
+        l = 0;
+#pragma unroll
+        for (int i = 1; i < kLevels; i++) if ((int)blockIdx.x >= ba.first[i]) l = i;
+        strip = (int)blockIdx.x - ba.first[l];
+        qcap = ba.qcap[l];
+    }
     // diagnostic build only (ARIA_STAMPS=1): phase boundaries of wave 0 of every workgroup, s_memtime ticks
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
 
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int frame = blockIdx.y;
-    const int y0 = blockIdx.x * RB;
+    const int y0 = strip * RB;
     int pitch;
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
 
@@ -519,58 +531,111 @@ int band_set_attributes() {
     return ARIA_OK;
 }
 
+int band_side_streams(LaunchCtx& ctx) {
+    if (ctx.ev_fork) return ARIA_OK;
+    ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_fork, hipEventDisableTiming));
+    for (int l = 0; l < kLevels; l++) {
+        ARIA_HIP(hipStreamCreateWithFlags(&ctx.side[l], hipStreamNonBlocking));
+        ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_join[l], hipEventDisableTiming));
+        ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_lvl[l], hipEventDisableTiming));
+    }
+    return ARIA_OK;
+}
+
 int band_init_ctx(LaunchCtx& ctx) {
     const EnvConfig& E = env_config();
     // The 8 levels are independent; ARIA_LEVEL_STREAMS=1 forks them onto side streams and joins back on the caller's
-    // stream (measured: no gain over back-to-back launches at chunk >= 256; off by default).
+    // stream (measured: no gain over back-to-back launches at chunk >= 256; off by default for batches, used by the
+    // single-frame latency schedule).
     if (E.level_streams) {
-        ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_fork, hipEventDisableTiming));
-        for (int l = 1; l < kLevels; l++) {
-            ARIA_HIP(hipStreamCreateWithFlags(&ctx.side[l], hipStreamNonBlocking));
-            ARIA_HIP(hipEventCreateWithFlags(&ctx.ev_join[l], hipEventDisableTiming));
-        }
+        int rc = band_side_streams(ctx);
+        if (rc != ARIA_OK) return rc;
     }
     if (E.stamp_level >= 0) ARIA_HIP(hipMalloc(&ctx.d_band_stamps, sizeof(unsigned long long) * 16 * 32768));
     return ARIA_OK;
 }
 
+// One level's launch on stream s (no stream orchestration here).
+static void band_launch_level(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t s, Profiler* prof,
+                              bool fuse_resize, LaunchCtx& ctx, int l) {
+    const EnvConfig& E = env_config();
+#ifdef ARIA_DIAG
+    const int ablate = E.ablate;      // timing experiments of diagnostic builds only: results are invalid when non-zero
+#else
+    const int ablate = 0;
+#endif
+    unsigned long long* d_stamps = ctx.d_band_stamps;
+    const int stamp_level = d_stamps ? E.stamp_level : -1;
+    const LevelGeom& g = P.lv[l];
+    const BandCfg c = band_cfg(P, g.w, l);
+    const int RB = c.nb * kBandR;
+    const dim3 grid((g.h + RB - 1) / RB, n_frames);
+    unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
+#define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
+                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1, D.tab, \
+                                         (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr, BandAll{})
+    if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
+    else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
+#undef ARIA_FB_LAUNCH
+    if (stp) {   // diagnostic: print mean phase lengths of this launch
+        hipStreamSynchronize(s);
+        const size_t nblk = (size_t)grid.x * grid.y;
+        std::vector<unsigned long long> hs(nblk * 8);
+        hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        double ph[7] = {0};
+        for (size_t b = 0; b < nblk; b++) for (int k = 0; k < 7; k++) ph[k] += (double)(hs[b * 8 + k + 1] - hs[b * 8 + k]);
+        fprintf(stderr, "[stamps L%d] blocks %zu, cycles: stage %.0f main+pyramid %.0f barrier %.0f score %.0f map %.0f nms %.0f out %.0f\n",
+                l, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, ph[4] / nblk, ph[5] / nblk, ph[6] / nblk);
+    }
+}
+
+// Batch schedule: 8 launches in level order on one stream (or, ARIA_LEVEL_STREAMS=1, forked onto side streams).
 void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
                            Profiler* prof, bool fuse_resize, LaunchCtx& ctx) {
     const EnvConfig& E = env_config();
-    const int ablate = E.ablate;
     const bool use_side = E.level_streams && ctx.ev_fork != nullptr;
-    hipStream_t* side = ctx.side;
-    hipEvent_t ev_fork = ctx.ev_fork;
-    hipEvent_t* ev_join = ctx.ev_join;
-    unsigned long long* d_stamps = ctx.d_band_stamps;
-    const int stamp_level = d_stamps ? E.stamp_level : -1;
-    if (use_side) hipEventRecord(ev_fork, st);
+    if (use_side) hipEventRecord(ctx.ev_fork, st);
+    for (int l = 0; l < kLevels; l++) {
+        hipStream_t s = (use_side && l > 0) ? ctx.side[l] : st;
+        if (use_side && l > 0) hipStreamWaitEvent(s, ctx.ev_fork, 0);
+        band_launch_level(P, S, D, n_frames, s, prof, fuse_resize, ctx, l);
+        if (use_side && l > 0) { hipEventRecord(ctx.ev_join[l], s); hipStreamWaitEvent(st, ctx.ev_join[l], 0); }
+    }
+}
+
+// Latency schedule of the single-frame path (captured into a hipGraph by orb_api.hip): with one frame a level's launch is a
+// few workgroups of ~20 us each, and what the caller waits for is the CHAIN of dependent launches (8 fused ones: ~200 us).
+// So the pyramid is built first -- one launch of the all-levels-in-LDS kernel k_pyramid when its bands fit, else the
+// 7-launch resize chain -- and then ONE launch runs the FAST/blur strips of all eight levels side by side.
+void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                                     Profiler* prof, LaunchCtx& ctx) {
+    (void)ctx;
+    if (!launch_pyramid_fused(P, S, D, n_frames, st, prof))
+        for (int l = 1; l < kLevels; l++) launch_pyramid_level(P, S, D, n_frames, st, prof, l);
+    BandAll ba{};
+    size_t lds = 0;
+    int nthr = 64, total = 0;
     for (int l = 0; l < kLevels; l++) {
         const LevelGeom& g = P.lv[l];
-        const BandCfg c = band_cfg(P, g.w, l);
-        const int RB = c.nb * kBandR;
-        const dim3 grid((g.h + RB - 1) / RB, n_frames);
-        hipStream_t s = (use_side && l > 0) ? side[l] : st;
-        if (use_side && l > 0) hipStreamWaitEvent(s, ev_fork, 0);
-        unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
-#define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
-                                         D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1, D.tab, \
-                                         (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr)
-        if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
-        else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
-#undef ARIA_FB_LAUNCH
-        if (use_side && l > 0) { hipEventRecord(ev_join[l], s); hipStreamWaitEvent(st, ev_join[l], 0); }
-        if (l == stamp_level && d_stamps) {   // diagnostic: print mean phase lengths of this launch
-            hipStreamSynchronize(s);
-            const size_t nblk = (size_t)grid.x * grid.y;
-            std::vector<unsigned long long> hs(nblk * 8);
-            hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-            double ph[7] = {0};
-            for (size_t b = 0; b < nblk; b++) for (int k = 0; k < 7; k++) ph[k] += (double)(hs[b * 8 + k + 1] - hs[b * 8 + k]);
-            fprintf(stderr, "[stamps L%d] blocks %zu, cycles: stage %.0f main+pyramid %.0f barrier %.0f score %.0f map %.0f nms %.0f out %.0f\n",
-                    l, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, ph[4] / nblk, ph[5] / nblk, ph[6] / nblk);
-        }
+        // one strip per workgroup at every level (nb = 1): same code path, uniform block size = the widest level's
+        const int wq = (g.w + 3) & ~3, lpr = wq >> 2;
+        const int qpct = std::min(50, P.band_qpct0 + P.band_qstep * l);
+        int qcap = (int)((int64_t)kBandR * wq * qpct / 100);
+        qcap = std::max(512, (qcap + 63) & ~63);
+        ba.first[l] = total;
+        ba.qcap[l] = qcap;
+        total += (g.h + kBandR - 1) / kBandR;
+        lds = std::max(lds, (size_t)(kBandR + 8) * (wq + 8) + 4 * (size_t)qcap);
+        nthr = std::max(nthr, ((lpr + 63) / 64) * 64);
     }
+    ba.first[kLevels] = total;
+    const dim3 grid(total, n_frames);
+    if (P.tie_mode == 1)
+        ARIA_LAUNCH(prof, (k_fast_blur_band<1, 1>), grid, dim3(nthr), lds, st, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
+                    0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
+    else
+        ARIA_LAUNCH(prof, (k_fast_blur_band<0, 1>), grid, dim3(nthr), lds, st, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
+                    0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
 }
 
 }  // namespace aria

@@ -43,17 +43,28 @@ struct aria_orb_s {
     // single-frame host path
     uint8_t* d_img = nullptr;
     uint8_t* h_img = nullptr;          // pinned
-    aria_keypoint* d_kps = nullptr;
+    // outputs of the single-frame path: ONE device block and one pinned block, [16-int header][kp_cap keypoint records]
+    // [kp_cap descriptor rows], so a frame comes back with one copy. Header: [0] count, [4] error bits, [5] slow-path
+    // blocks, [6] rows needed (D.err points at header word 4 of the device block).
+    uint8_t* d_out = nullptr;
+    uint8_t* h_out = nullptr;          // pinned
+    aria_keypoint* d_kps = nullptr;    // views into d_out / h_out
     uint8_t* d_desc = nullptr;
     int* d_count = nullptr;
-    aria_keypoint* h_kps = nullptr;    // pinned
-    uint8_t* h_desc = nullptr;         // pinned
-    int* h_count = nullptr;            // pinned: [0] count, [1] err bits
+    aria_keypoint* h_kps = nullptr;
+    uint8_t* h_desc = nullptr;
+    int* h_count = nullptr;            // = header of h_out
     bool pending = false;
 
     FrameSrc last_src{};
     bool have_last = false;
     Profiler prof;
+    // single-frame latency path: the whole enqueue sequence (H2D, resize chain, 8 parallel FAST/blur branches, select,
+    // describe, D2H) captured once per (plan, buffers) into a hipGraph and replayed
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_w = 0, graph_h = 0, graph_nf = 0, graph_cap = 0, graph_q = 0;
+    bool graph_failed = false;      // capture or instantiate failed once: stay on eager launches
     LaunchCtx ctx;          // per-handle launch state (function attributes of this device, side streams, stamp buffers)
 };
 
@@ -61,15 +72,22 @@ namespace {
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+void drop_graph(aria_orb_s* h) {
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr;
+    h->graph = nullptr;
+}
+
 void free_scratch(aria_orb_s* h) {
-    hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand); hipFree(h->D.cand_cnt);
-    hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.pyr_bands); hipFree(h->D.err);
-    hipFree(h->D.ovf); hipFree(h->D.ovf_items); hipFree(h->D.ovf_keys); hipFree(h->D.osel);
-    hipFree(h->d_img); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_count);
+    drop_graph(h);              // the captured sequence points into the buffers freed below
+    hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand);     // (D.cand_cnt lives behind D.ovf)
+    hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.pyr_bands);    // (D.err lives inside d_out)
+    hipFree(h->D.ovf); hipFree(h->D.ovf_keys); hipFree(h->D.osel);
+    hipFree(h->d_img); hipFree(h->d_out);
     if (h->h_img) hipHostFree(h->h_img);
-    if (h->h_kps) hipHostFree(h->h_kps);
-    if (h->h_desc) hipHostFree(h->h_desc);
-    if (h->h_count) hipHostFree(h->h_count);
+    if (h->h_out) hipHostFree(h->h_out);
+    h->d_out = nullptr; h->h_out = nullptr;
     h->D = DeviceScratch{};
     h->d_img = nullptr; h->d_kps = nullptr; h->d_desc = nullptr; h->d_count = nullptr;
     h->h_img = nullptr; h->h_kps = nullptr; h->h_desc = nullptr; h->h_count = nullptr;
@@ -85,6 +103,8 @@ void note_slow_blocks(aria_orb_s* h, int n) {
     if (h->band_qpct0 < 50) h->band_qpct0 = std::min(50, h->band_qpct0 + 10);
 }
 
+int alloc_io(aria_orb_s* h, int rows);
+
 int alloc_scratch(aria_orb_s* h) {
     Plan mp;
     int64_t tabn = plan_tab_entries(h->max_w, h->max_h) + 64;
@@ -99,36 +119,30 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipMalloc(&h->D.raw, std::max<size_t>(mp.raw_frame_bytes * B, 256)));
     ARIA_HIP(hipMalloc(&h->D.blur, std::max<size_t>(mp.blur_frame_bytes * B, 256)));
     ARIA_HIP(hipMalloc(&h->D.cand, sizeof(uint32_t) * (size_t)mp.cand_frame_entries * B));
-    ARIA_HIP(hipMalloc(&h->D.cand_cnt, sizeof(int) * kLevels * B));
+    // [4 tie-storm arena counters][8 candidate counters per frame]: zeroed together by one memset per pass
+    ARIA_HIP(hipMalloc(&h->D.ovf, sizeof(int) * (4 + kLevels * B)));
+    h->D.cand_cnt = h->D.ovf + 4;
     ARIA_HIP(hipMalloc(&h->D.sel, sizeof(uint4) * (size_t)mp.sel_frame_entries * B));
     ARIA_HIP(hipMalloc(&h->D.sel_cnt, sizeof(int) * kLevels * B));
     ARIA_HIP(hipMalloc(&h->D.tab, sizeof(uint32_t) * (size_t)tabn));
     h->bands_host.assign((size_t)((h->max_h + 7) / 8) * kLevels * 4 + 64, 0);
     ARIA_HIP(hipMalloc(&h->D.pyr_bands, sizeof(int) * h->bands_host.size()));
-    // [0] deferred error bits, [1] band-kernel slow-path blocks, [2] rows needed by the largest frame that did not fit kp_cap
-    ARIA_HIP(hipMalloc(&h->D.err, 4 * sizeof(int)));
-    ARIA_HIP(hipMemset(h->D.err, 0, 4 * sizeof(int)));
+    // D.err ([0] deferred error bits, [1] band-kernel slow-path blocks, [2] rows needed by the largest frame that did not
+    // fit kp_cap) is part of the single-frame output block: alloc_io below
     // tie-storm arenas: room for the worst case of four whole frames per pass (every FAST candidate of every level tied)
     {
         long long per_frame = 0;
         for (int l = 0; l < kLevels; l++) { long long np = 1; while (np < mp.lv[l].cand_cap) np <<= 1; per_frame += np; }
         h->D.ovf_keys_cap = 4 * per_frame;
         h->D.osel_cap = (int)std::min<long long>(4 * (long long)mp.cand_frame_entries + 64, 1ll << 24);
-        ARIA_HIP(hipMalloc(&h->D.ovf, 4 * sizeof(int)));
-        ARIA_HIP(hipMemset(h->D.ovf, 0, 4 * sizeof(int)));
-        ARIA_HIP(hipMalloc(&h->D.ovf_items, sizeof(int2) * kOvfItems));
         ARIA_HIP(hipMalloc(&h->D.ovf_keys, sizeof(unsigned long long) * (size_t)h->D.ovf_keys_cap));
         ARIA_HIP(hipMalloc(&h->D.osel, sizeof(uint4) * (size_t)h->D.osel_cap));
     }
     const size_t img_bytes = (size_t)align_up(h->max_w, 16) * h->max_h;
     ARIA_HIP(hipMalloc(&h->d_img, img_bytes));
     ARIA_HIP(hipHostMalloc(&h->h_img, img_bytes));
-    ARIA_HIP(hipMalloc(&h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
-    ARIA_HIP(hipMalloc(&h->d_desc, 32 * (size_t)h->kp_cap));
-    ARIA_HIP(hipMalloc(&h->d_count, sizeof(int)));
-    ARIA_HIP(hipHostMalloc(&h->h_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap));
-    ARIA_HIP(hipHostMalloc(&h->h_desc, 32 * (size_t)h->kp_cap));
-    ARIA_HIP(hipHostMalloc(&h->h_count, 8 * sizeof(int)));
+    rc = alloc_io(h, h->kp_cap);
+    if (rc != ARIA_OK) return rc;
     h->plan_valid = false;
     return ARIA_OK;
 }
@@ -163,7 +177,6 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     if (rc != ARIA_OK) return rc;
     const int pitch = align_up(width, 16);
     for (int y = 0; y < height; y++) std::memcpy(h->h_img + (size_t)y * pitch, image + (size_t)y * stride, (size_t)width);
-    ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, (size_t)pitch * height, hipMemcpyHostToDevice, h->stream));
     FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1, (pitch % 16 == 0 && ((int64_t)pitch * height) % 16 == 0) ? 1 : 0};
     h->last_src = S;
     h->have_last = true;
@@ -173,46 +186,91 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
 // Internal single-frame output buffers (rows = kp_cap). A tie storm can return more keypoints than the plan's slots
 // (OpenCV keeps every tie): the buffers then grow to what the frame needs and the frame is run again.
 int alloc_io(aria_orb_s* h, int rows) {
-    hipFree(h->d_kps); hipFree(h->d_desc);
-    if (h->h_kps) hipHostFree(h->h_kps);
-    if (h->h_desc) hipHostFree(h->h_desc);
-    h->d_kps = nullptr; h->d_desc = nullptr; h->h_kps = nullptr; h->h_desc = nullptr;
+    rows = (rows + 3) & ~3;
+    hipFree(h->d_out);
+    if (h->h_out) hipHostFree(h->h_out);
+    h->d_out = nullptr; h->h_out = nullptr;
     h->kp_cap = rows;
-    ARIA_HIP(hipMalloc(&h->d_kps, sizeof(aria_keypoint) * (size_t)rows));
-    ARIA_HIP(hipMalloc(&h->d_desc, 32 * (size_t)rows));
-    ARIA_HIP(hipHostMalloc(&h->h_kps, sizeof(aria_keypoint) * (size_t)rows));
-    ARIA_HIP(hipHostMalloc(&h->h_desc, 32 * (size_t)rows));
+    const size_t bytes = 64 + (size_t)rows * (sizeof(aria_keypoint) + 32);
+    ARIA_HIP(hipMalloc(&h->d_out, bytes));
+    ARIA_HIP(hipHostMalloc(&h->h_out, bytes));
+    ARIA_HIP(hipMemset(h->d_out, 0, 64));
+    std::memset(h->h_out, 0, 64);
+    h->d_count = reinterpret_cast<int*>(h->d_out);
+    h->D.err = reinterpret_cast<int*>(h->d_out) + 4;
+    h->d_kps = reinterpret_cast<aria_keypoint*>(h->d_out + 64);
+    h->d_desc = h->d_out + 64 + (size_t)rows * sizeof(aria_keypoint);
+    h->h_count = reinterpret_cast<int*>(h->h_out);
+    h->h_kps = reinterpret_cast<aria_keypoint*>(h->h_out + 64);
+    h->h_desc = h->h_out + 64 + (size_t)rows * sizeof(aria_keypoint);
     return ARIA_OK;
 }
 
+int enqueue_single_ops(aria_orb_s* h);
+
+// Replays (capturing it first when the plan or the buffers changed) the single-frame sequence as a hipGraph. Eager
+// launches when profiling brackets are on (they synchronise the stream) or ARIA_SINGLE_GRAPH=0.
 int launch_single(aria_orb_s* h) {
+    static const bool want_graph = [] { const char* e = getenv("ARIA_SINGLE_GRAPH"); return !(e && e[0] == '0'); }();
+    const bool diag = env_config().stamp_level >= 0 || env_config().sel_stamps || env_config().desc_stamps;
+    if (!want_graph || h->graph_failed || h->prof.enabled || diag) { h->ctx.schedule = 0; return enqueue_single_ops(h); }
+    if (band_side_streams(h->ctx) != ARIA_OK) { h->graph_failed = true; h->ctx.schedule = 0; return enqueue_single_ops(h); }
+    const bool stale = !h->graph_exec || h->graph_w != h->plan.width || h->graph_h != h->plan.height ||
+                       h->graph_nf != h->max_features || h->graph_cap != h->kp_cap || h->graph_q != h->plan.band_qpct0;
+    if (stale) {
+        drop_graph(h);
+        h->ctx.schedule = 1;
+        // whatever is queued on the stream (plan tables of ensure_plan) must be done before the capture starts
+        ARIA_HIP(hipStreamSynchronize(h->stream));
+        hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+        int rc = ARIA_OK;
+        if (e == hipSuccess) {
+            rc = enqueue_single_ops(h);
+            e = hipStreamEndCapture(h->stream, &h->graph);
+        }
+        if (e == hipSuccess && rc == ARIA_OK) e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess || rc != ARIA_OK || !h->graph_exec) {
+            drop_graph(h);
+            (void)hipGetLastError();
+            h->graph_failed = true;
+            h->ctx.schedule = 0;
+            return enqueue_single_ops(h);
+        }
+        h->graph_w = h->plan.width; h->graph_h = h->plan.height; h->graph_nf = h->max_features; h->graph_cap = h->kp_cap;
+        h->graph_q = h->plan.band_qpct0;
+    }
+    ARIA_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+    return ARIA_OK;
+}
+
+int enqueue_single_ops(aria_orb_s* h) {
+    const size_t img_bytes = (size_t)h->last_src.row_stride * h->plan.height;
+    ARIA_HIP(hipMemsetAsync(h->d_out, 0, 64, h->stream));        // count + the deferred error words of this frame
+    ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, h->stream));
     launch_extract_chunk(h->plan, h->last_src, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof, h->ctx);
     ARIA_HIP(hipGetLastError());
-    ARIA_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(aria_keypoint) * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, 32 * (size_t)h->kp_cap, hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemcpyAsync(&h->h_count[0], h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemcpyAsync(&h->h_count[1], h->D.err, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    ARIA_HIP(hipMemsetAsync(h->D.err, 0, 4 * sizeof(int), h->stream));
+    // the whole result in one copy: header (count, error words) + keypoints + descriptors
+    ARIA_HIP(hipMemcpyAsync(h->h_out, h->d_out, 64 + (size_t)h->kp_cap * (sizeof(aria_keypoint) + 32), hipMemcpyDeviceToHost, h->stream));
     return ARIA_OK;
 }
 
 int finish_single(aria_orb_s* h, aria_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     ARIA_HIP(hipStreamSynchronize(h->stream));
-    if ((h->h_count[1] & ERRBIT_KPCAP) && h->h_count[3] > h->kp_cap) {
+    if ((h->h_count[4] & ERRBIT_KPCAP) && h->h_count[6] > h->kp_cap) {
         // the frame has more keypoints than the internal buffers hold (ties): grow them and run the frame again
         // (its image is still in the handle's device copy)
-        const int need = (h->h_count[3] + 63) & ~63;
+        const int need = (h->h_count[6] + 63) & ~63;
         int rc = alloc_io(h, need);
         if (rc != ARIA_OK) return rc;
         rc = launch_single(h);
         if (rc != ARIA_OK) return rc;
         ARIA_HIP(hipStreamSynchronize(h->stream));
     }
-    const int errbits = h->h_count[1];
-    note_slow_blocks(h, h->h_count[2]);
+    const int errbits = h->h_count[4];
+    note_slow_blocks(h, h->h_count[5]);
     int st = errbits_to_status(errbits & ~ERRBIT_KPCAP);
     if (st != ARIA_OK) { if (n_out) *n_out = 0; return st; }
-    const int n = (errbits & ERRBIT_KPCAP) ? std::max(h->h_count[3], h->h_count[0]) : h->h_count[0];
+    const int n = (errbits & ERRBIT_KPCAP) ? std::max(h->h_count[6], h->h_count[0]) : h->h_count[0];
     h->last_n = n;
     if (n_out) *n_out = n;
     if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
@@ -303,6 +361,7 @@ void aria_orb_destroy(aria_orb_t h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     h->prof.release();
+    drop_graph(h);
     h->ctx.release();
     free_scratch(h);
     if (h->owns_stream && h->stream) hipStreamDestroy(h->stream);
@@ -386,6 +445,7 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
     if (rc != ARIA_OK) return rc;
     const int aligned4 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
     const int aligned16 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
+    h->ctx.schedule = 0;        // batches use the throughput schedule
     for (int f0 = 0; f0 < n_frames; f0 += h->max_batch) {
         const int nf = std::min(h->max_batch, n_frames - f0);
         FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4, aligned16};

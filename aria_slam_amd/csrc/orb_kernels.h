@@ -32,10 +32,9 @@ struct DeviceScratch {
     uint32_t* tab;       // resize coefficient tables (ofs | c1 << 16)
     int* pyr_bands;      // [pyr_nbands][8][4] row ranges of the fused pyramid kernel
     int* err;            // deferred error bits
-    // tie-storm fallback (k_select_ovf): work list of (frame, level) pairs whose ties overflow k_select's LDS capacities,
-    // a key arena for the global-memory sort and an arena of selected keypoints beyond a level's regular slots
-    int* ovf;            // [0] items, [1] osel entries used, [2..3] key-arena entries used (64-bit)
-    int2* ovf_items;     // [kOvfItems]
+    // tie-storm fallback (select_ovf_item): a key arena for the global-memory sort of (frame, level) pairs whose ties
+    // overflow k_select's LDS capacities, and an arena of selected keypoints beyond a level's regular slots
+    int* ovf;            // [1] osel entries used, [2..3] key-arena entries used (64-bit)
     unsigned long long* ovf_keys;
     long long ovf_keys_cap;
     uint4* osel;
@@ -89,8 +88,13 @@ const EnvConfig& env_config();
 
 struct LaunchCtx {
     int device = -1;
+    // 0: batch schedule (pyramid fused into the FAST/blur launches, everything on one stream: best throughput);
+    // 1: latency schedule of the single-frame host path: stand-alone resize chain, then the 8 levels' FAST/blur launches
+    //    as parallel branches (side streams; captured into a hipGraph by orb_api.hip), because with one frame a level's
+    //    launch is a handful of workgroups and the chain of 8 dependent launches is what the caller waits for
+    int schedule = 0;
     hipStream_t side[kLevels] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {}, ev_lvl[kLevels] = {};
     unsigned long long* d_band_stamps = nullptr;
     unsigned long long* d_sel_stamps = nullptr;
     unsigned long long* d_desc_stamps = nullptr;
@@ -116,6 +120,18 @@ void launch_band2(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int 
 int band2_set_attributes();
 int band_set_attributes();          // hipFuncSetAttribute of the band kernels on the current device (aria_status)
 int band_init_ctx(LaunchCtx& ctx);  // side streams / stamp buffer when the environment asks for them
+int band_side_streams(LaunchCtx& ctx);   // create the per-level side streams + fork/join events (idempotent)
+
+// stand-alone pyramid pass (pyramid_pass.hip) and the tile form of the FAST/blur stage (fast_blur_tile.hip)
+// strips of all levels in one launch of the band kernel (single-frame latency schedule): first[l] = first blockIdx.x of level l
+struct BandAll { int first[kLevels + 1]; int qcap[kLevels]; };
+bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof);
+void launch_pyramid_level(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof, int l);
+void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                                     Profiler* prof, LaunchCtx& ctx);
+void launch_pyramid_pass(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof);
+int pyramid_set_attributes();
+void launch_fast_blur_tile(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof);
 
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,

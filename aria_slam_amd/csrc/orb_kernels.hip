@@ -1,15 +1,15 @@
 // HIP kernels of the ORB extractor for gfx950 (MI355X). Wave = 64 lanes throughout.
 //
 // Stage map (algorithm = CPU cv::ORB of OpenCV 4.9.0):
-//   k_resize      a6.1  pyramid level l from level l-1, INTER_LINEAR_EXACT fixed point (8+8 fractional bits)
-//   k_fast_blur   a6.2  FAST-9/16 score + 3x3 strict-max NMS + 31-px border filter -> candidate list
-//                 a6.7  7x7 sigma-2 Gaussian (8-bit fixed-point separable) of the same LDS tile -> blurred level
+//   (fast_blur_band.hip: a6.1 pyramid step, a6.2 FAST-9 + NMS, a6.3 border filter, a6.7 7x7 Gaussian -- the dominant kernel;
+//    pyramid_pass.hip: the stand-alone a6.1 resize pass of the single-frame latency schedule)
 //   k_select      a6.3  retainBest(2*quota) by FAST score (256-bin histogram cut, ties kept)
 //                 a6.4  Harris response (block 7, k 0.04) of the survivors
 //                 a6.5  retainBest(quota) by Harris (LDS bitonic sort, ties kept) -> canonical order
-//   k_describe    a6.6  intensity-centroid angle (one wave per keypoint, integer moments, fastAtan2)
-//                 a6.8  256-bit rBRIEF: lane i evaluates tests i, i+64, i+128, i+192; four 64-bit ballots are
-//                       exactly the 32 descriptor bytes (LSB-first)
+//   k_select_ovf  the same selection in global memory for (frame, level) pairs whose ties overflow k_select's LDS capacities
+//   k_describe    a6.6  intensity-centroid angle (one keypoint per 16-lane DPP row, integer moments, fastAtan2)
+//                 a6.8  256-bit rBRIEF: lane l16 of a row evaluates tests 16*it + l16; one 64-bit ballot per iteration
+//                       carries 16 descriptor bits for each of the wave's four keypoints (LSB-first bytes)
 // All of it is HBM/LDS/VALU-integer work; nothing here is a dense contraction, so no MFMA.
 // Float stages are compiled with -ffp-contract=off so that they round exactly like the SSE3-baseline
 // OpenCV build the CPU reference path uses (no FMA).
@@ -69,543 +69,6 @@ constexpr IcMaskLaneMajor make_ic_mask() {
     return t;
 }
 __device__ __attribute__((aligned(16))) const IcMaskLaneMajor kIcMask = make_ic_mask();
-
-// ------------------------------------------------------------------------------------------------------
-// a6.1  resize.cpp resize_bitExact<uchar, interpolationLinear>: H = c0*p[o] + c1*p[o+1] (exact, 8 frac bits),
-//       out = (cy0*H0 + cy1*H1 + 32768) >> 16. One thread = 4 adjacent output pixels = one dword store.
-// ------------------------------------------------------------------------------------------------------
-// Two bytes p[o], p[o+1] out of a 12-byte window (w0,w1,w2) that starts at byte `base`; e = o - base in [0, 7].
-__device__ __forceinline__ uint32_t window_pair(uint32_t w0, uint32_t w1, uint32_t w2, int e) {
-    const uint32_t lo = e < 4 ? w0 : w1, hi = e < 4 ? w1 : w2;
-    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)e);    // uses e & 3
-}
-
-constexpr int kResizeRows = 8;   // output rows per thread
-
-// One thread = 4 adjacent output pixels x 8 output rows. The level's x table and the block's slice of the y table
-// are staged in LDS with one coalesced round trip; after that the only global accesses are the source rows
-// (3 aligned dwords per source row, 4 rows = 24 loads in flight per lane) and the dword stores.
-__global__ __launch_bounds__(256) void k_resize(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
-                                                const uint32_t* __restrict__ tab, int l) {
-    extern __shared__ uint32_t s_rt[];        // [w] x table, then [kResizeRows * (rc1 - rc0 + 1)] y slice
-    const LevelGeom g = P.lv[l];
-    const int frame = blockIdx.y;
-    const int groups = g.pitch >> 2;
-    const int nrc = (g.h + kResizeRows - 1) / kResizeRows;
-    const int total = groups * nrc;
-    const int gid0 = blockIdx.x * 256;
-    const int rc_first = gid0 / groups, rc_last = min(gid0 + 255, total - 1) / groups;
-    uint32_t* s_yt = s_rt + g.w;
-    for (int i = threadIdx.x; i < g.w; i += 256) s_rt[i] = tab[g.xtab + i];
-    {
-        const int y0 = rc_first * kResizeRows, ny = min((rc_last + 1) * kResizeRows, g.h) - y0;
-        for (int i = threadIdx.x; i < ny; i += 256) s_yt[i] = tab[g.ytab + y0 + i];
-    }
-    __syncthreads();
-    const int gid = gid0 + threadIdx.x;
-    if (gid >= total) return;
-    const int rc = gid / groups, gx = gid - rc * groups;
-    int spitch;
-    const uint8_t* src = raw_level_ptr(P, S, raw, frame, l - 1, spitch);
-    const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
-    uint8_t* dst = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off + gx * 4;
-    const int dx0 = gx * 4;
-    const int dy0 = rc * kResizeRows;
-    const uint32_t* yt = s_yt + (rc - rc_first) * kResizeRows;
-    if (dx0 >= g.w) {   // row padding up to the 16-byte pitch: keep it deterministic
-        for (int r = 0; r < kResizeRows && dy0 + r < g.h; r++) *reinterpret_cast<uint32_t*>(dst + (int64_t)(dy0 + r) * g.pitch) = 0u;
-        return;
-    }
-    uint32_t tx[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) tx[i] = s_rt[min(dx0 + i, g.w - 1)];
-    const int base = (int)(tx[0] & 0xFFFF) & ~3;
-    int e[4], cx1[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { e[i] = (int)(tx[i] & 0xFFFF) - base; cx1[i] = (int)(tx[i] >> 16); }
-    // dword path: 3 aligned dwords per source row cover the <= 9 source bytes four outputs need (scale ~1.2). Only
-    // the last threads of a row of an unpadded / unaligned caller image take the byte path.
-    const bool fast = (l > 1 || S.aligned4) && (base + 12 <= spitch) && e[3] <= 7;
-    if (fast) {
-#pragma unroll 4
-        for (int r = 0; r < kResizeRows; r++) {
-            const int dy = dy0 + r;
-            if (dy < g.h) {
-                const uint32_t ty = yt[r];
-                const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
-                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (int64_t)oy * spitch + base);
-                const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (int64_t)min(oy + 1, sh - 1) * spitch + base);
-                const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
-                const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
-                uint32_t outw = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t pa = window_pair(a0, a1, a2, e[i]), pb = window_pair(b0, b1, b2, e[i]);
-                    const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
-                    // c0*p0 + c1*p1 with c0 = 256 - c1  ==  256*p0 + c1*(p1 - p0)   (exact, same integers)
-                    const int h0 = (p00 << 8) + cx1[i] * (p01 - p00);
-                    const int h1 = (p10 << 8) + cx1[i] * (p11 - p10);
-                    const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
-                    outw |= min(v, 255u) << (8 * i);
-                }
-                *reinterpret_cast<uint32_t*>(dst + (int64_t)dy * g.pitch) = outw;
-            }
-        }
-    } else {
-        for (int r = 0; r < kResizeRows; r++) {
-            const int dy = dy0 + r;
-            if (dy >= g.h) break;
-            const uint32_t ty = yt[r];
-            const int oy = ty & 0xFFFF;
-            const uint32_t cyy1 = ty >> 16, cyy0 = 256u - cyy1;
-            const uint8_t* r0 = src + (int64_t)oy * spitch;
-            const uint8_t* r1 = src + (int64_t)min(oy + 1, sh - 1) * spitch;
-            uint32_t outw = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (dx0 + i < g.w) {
-                    const int ox = tx[i] & 0xFFFF, ox1 = min(ox + 1, sw - 1);
-                    const uint32_t c1 = tx[i] >> 16, c0 = 256u - c1;
-                    const uint32_t h0 = c0 * r0[ox] + c1 * r0[ox1];
-                    const uint32_t h1 = c0 * r1[ox] + c1 * r1[ox1];
-                    const uint32_t v = (cyy0 * h0 + cyy1 * h1 + 32768u) >> 16;
-                    outw |= min(v, 255u) << (8 * i);
-                }
-            }
-            *reinterpret_cast<uint32_t*>(dst + (int64_t)dy * g.pitch) = outw;
-        }
-    }
-}
-
-// a6.1, LDS-staged form: a workgroup produces kResizeBand output rows of level l. The source rows it needs
-// (~1.2 * band + 2) are staged with coalesced 16-byte loads, 4 in flight per lane, so the texture path sees wide
-// contiguous requests instead of three overlapping dword gathers per lane; the x table and the band's y slice ride
-// along in LDS; the bilinear taps are then dword windows read from LDS.
-//
-// DOT2 (default): the per-pixel arithmetic runs on v_perm_b32 + v_dot2_u32_u16. The x table is widened at staging
-// time to three words per output column -- (256-cx1) | cx1 << 16, the dword-aligned source offset, and the v_perm
-// selector that lifts the two source bytes into two u16 lanes -- kept as three arrays so that a lane fetches the four
-// columns of its output dword with three conflict-free ds_read_b128. A pixel is then: two ds_read2_b32 (source
-// dword pair in both rows), 2 v_perm + 2 v_dot2 (horizontal pass, both rows), 1 v_lshl_or + 1 v_dot2 with
-// the rounding constant as accumulator (vertical pass), 1 v_perm that drops the result byte into the output dword:
-// 9 vector-ALU instructions per pixel where the shift/extract/mad form needed ~30 (this kernel is VALU-issue bound).
-// Same integers as the reference's ufixedpoint16 arithmetic: (256-c)*p0 + c*p1 is what it evaluates.
-constexpr int kResizeBand = 16;
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-template <bool DOT2>
-__global__ __launch_bounds__(256) void k_resize_lds(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
-                                                    const uint32_t* __restrict__ tab, int l) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_rs[];
-    const LevelGeom g = P.lv[l];
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.y;
-    const int dy0 = blockIdx.x * kResizeBand, ndy = min(kResizeBand, g.h - dy0);
-    int spitch;
-    const uint8_t* src = raw_level_ptr(P, S, raw, frame, l - 1, spitch);
-    const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
-    const int lp = (sw + 15) / 16 * 16 + 16;                     // LDS pitch of a staged source row (+16: window slack)
-    const int max_rows = (kResizeBand * 13) / 10 + 4;            // rows a band can need at scale ~1.2
-    uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_rs + max_rows * lp);      // 16-byte aligned: lp is a multiple of 16
-    const int w4 = (g.w + 3) & ~3;
-    uint32_t* s_yt = s_xt + (DOT2 ? 3 * w4 : g.w);
-    const uint32_t* ytg = tab + g.ytab + dy0;
-    const int oy_lo = (int)(ytg[0] & 0xFFFF);
-    const int oy_hi = min((int)(ytg[ndy - 1] & 0xFFFF) + 1, sh - 1);
-    const int nrows = min(oy_hi - oy_lo + 1, max_rows);
-    if (DOT2) {
-        for (int i = tid; i < w4; i += 256) {                 // columns past the level repeat the last one
-            const uint32_t t = tab[g.xtab + min(i, g.w - 1)];
-            const uint32_t ox = t & 0xFFFFu, cx1 = t >> 16;
-            s_xt[i] = (256u - cx1) | (cx1 << 16);
-            s_xt[w4 + i] = ox & ~3u;
-            s_xt[2 * w4 + i] = 0x0C010C00u + (ox & 3u) * 0x00010001u;
-        }
-    } else {
-        for (int i = tid; i < g.w; i += 256) s_xt[i] = tab[g.xtab + i];
-    }
-    if (tid < ndy) s_yt[tid] = ytg[tid];
-    const bool a16 = (l > 1) || S.aligned16;
-    const int nch = a16 ? (sw >> 4) : 0;
-    if (nch > 0 && nch <= 256) {
-        const int rpp = 256 / nch;
-        const int my_r = tid / nch, my_c = tid - my_r * nch;
-        if (my_r < rpp) {
-            for (int r0 = my_r; r0 < nrows; r0 += 4 * rpp) {
-                uint4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int r = r0 + k * rpp;
-                    if (r < nrows) v[k] = *reinterpret_cast<const uint4*>(src + (int64_t)(oy_lo + r) * spitch + 16 * my_c);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int r = r0 + k * rpp;
-                    if (r < nrows) *reinterpret_cast<uint4*>(smem_rs + r * lp + 16 * my_c) = v[k];
-                }
-            }
-        }
-    }
-    {
-        const int xe0 = (nch > 0 && nch <= 256) ? nch * 16 : 0;
-        const int ne = sw - xe0;
-        for (int i = tid; i < nrows * ne; i += 256) {
-            const int r = i / ne, c = xe0 + (i - r * ne);
-            smem_rs[r * lp + c] = src[(int64_t)(oy_lo + r) * spitch + c];
-        }
-    }
-    __syncthreads();
-
-    uint8_t* dg = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
-    const int groups = g.pitch >> 2;
-    const int items = ndy * groups;
-    const float inv_groups = 1.0f / (float)groups;
-    for (int it = tid; it < items; it += 256) {
-        int r = (int)((float)it * inv_groups);
-        if (r * groups > it) r--;
-        else if ((r + 1) * groups <= it) r++;
-        const int gx = it - r * groups;
-        const int dx0 = gx * 4;
-        uint32_t outw = 0;
-        if (DOT2) {
-            if (dx0 < g.w) {
-                const uint32_t ty = s_yt[r];
-                const int oy = ty & 0xFFFF;
-                const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
-                const int ra = min(oy - oy_lo, nrows - 1), rb = min(min(oy + 1, sh - 1) - oy_lo, nrows - 1);
-                const uint8_t* rowa = smem_rs + ra * lp;
-                const uint8_t* rowb = smem_rs + rb * lp;
-                const uint4 xw = *reinterpret_cast<const uint4*>(s_xt + dx0);
-                const uint4 xo = *reinterpret_cast<const uint4*>(s_xt + w4 + dx0);
-                const uint4 xs = *reinterpret_cast<const uint4*>(s_xt + 2 * w4 + dx0);
-                const uint32_t xwv[4] = {xw.x, xw.y, xw.z, xw.w}, xov[4] = {xo.x, xo.y, xo.z, xo.w},
-                               xsv[4] = {xs.x, xs.y, xs.z, xs.w};
-                constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xov[i]);
-                    const uint32_t* qb = reinterpret_cast<const uint32_t*>(rowb + xov[i]);
-                    const uint32_t top = __builtin_amdgcn_perm(qa[1], qa[0], xsv[i]);     // p00 | p01 << 16
-                    const uint32_t bot = __builtin_amdgcn_perm(qb[1], qb[0], xsv[i]);
-                    const us2 wx = __builtin_bit_cast(us2, xwv[i]);
-                    const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, top), wx, 0u, false);
-                    const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bot), wx, 0u, false);
-                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, h0 | (h1 << 16)),
-                                                              __builtin_bit_cast(us2, cyp), 32768u, false);   // < 2^24
-                    outw = __builtin_amdgcn_perm(v, outw, put[i]);
-                }
-            }
-        } else if (dx0 < g.w) {
-            const uint32_t ty = s_yt[r];
-            const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
-            uint32_t tx[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) tx[i] = s_xt[min(dx0 + i, g.w - 1)];
-            const int base = (int)(tx[0] & 0xFFFF) & ~3;
-            const int ra = min(oy - oy_lo, nrows - 1), rb = min(min(oy + 1, sh - 1) - oy_lo, nrows - 1);
-            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(smem_rs + ra * lp + base);
-            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(smem_rs + rb * lp + base);
-            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
-            const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int e = min((int)(tx[i] & 0xFFFF) - base, 7), cx1 = (int)(tx[i] >> 16);
-                const uint32_t pa = window_pair(a0, a1, a2, e), pb = window_pair(b0, b1, b2, e);
-                const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
-                const int h0 = (p00 << 8) + cx1 * (p01 - p00);      // == (256-cx1)*p00 + cx1*p01
-                const int h1 = (p10 << 8) + cx1 * (p11 - p10);
-                const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
-                outw |= min(v, 255u) << (8 * i);
-            }
-        }
-        *reinterpret_cast<uint32_t*>(dg + (int64_t)(dy0 + r) * g.pitch + dx0) = outw;
-    }
-}
-
-// a6.1 fused: one workgroup builds levels 1..7 for a band of level-0 rows entirely in LDS: the level-0 band, the x
-// tables and each level's y-table slice are staged once, level l is resized from the level l-1 rows the same workgroup
-// just produced, and every row it owns goes to HBM exactly once. Nothing is re-read from HBM between levels, no item
-// waits on a global load, and the 7 dependent launches collapse into one.
-__global__ __launch_bounds__(256) void k_pyramid(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
-                                                 const uint32_t* __restrict__ tab, const int* __restrict__ bands) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_pyr[];
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.y;
-    const int* B = bands + (int)blockIdx.x * kLevels * 4;
-    uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_pyr + P.pyr_xtab_off);
-    uint32_t* s_yt = reinterpret_cast<uint32_t*>(smem_pyr + P.pyr_ytab_off);
-    const int xt_lo = P.lv[1].xtab;
-
-    // ---- stage: x tables, y slice of level 1, level-0 rows [comp_lo, comp_lo + comp_n) ----
-    for (int i = tid; i < P.pyr_xtab_n; i += 256) s_xt[i] = tab[xt_lo + i];
-    {
-        const int clo = B[4 + 0], cn = B[4 + 1];
-        if (tid < cn) s_yt[tid] = tab[P.lv[1].ytab + clo + tid];
-    }
-    {
-        const int lo0 = B[0], n0 = B[1], w0 = P.lv[0].w, p0 = P.pyr_p0;
-        const uint8_t* img = S.img + (int64_t)frame * S.frame_stride;
-        uint8_t* d0 = smem_pyr + P.pyr_off[0];
-        const int nch = S.aligned16 ? (w0 >> 4) : 0;
-        if (nch > 0) {
-            const int rpp = 256 / nch > 0 ? 256 / nch : 1;
-            const int my_r = tid / nch, my_c = tid - my_r * nch;
-            if (my_r < rpp && nch <= 256) {
-                for (int r0 = my_r; r0 < n0; r0 += 4 * rpp) {
-                    uint4 v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int r = r0 + k * rpp;
-                        if (r < n0) v[k] = *reinterpret_cast<const uint4*>(img + (int64_t)(lo0 + r) * S.row_stride + 16 * my_c);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int r = r0 + k * rpp;
-                        if (r < n0) *reinterpret_cast<uint4*>(d0 + r * p0 + 16 * my_c) = v[k];
-                    }
-                }
-            }
-        }
-        const int xe0 = (nch > 0 && nch <= 256) ? nch * 16 : 0;     // columns not covered by the 16-byte chunks
-        const int ne = w0 - xe0;
-        for (int i = tid; i < n0 * ne; i += 256) {
-            const int r = i / ne, c = xe0 + (i - r * ne);
-            d0[r * p0 + c] = img[(int64_t)(lo0 + r) * S.row_stride + c];
-        }
-    }
-    __syncthreads();
-
-    for (int l = 1; l < kLevels; l++) {
-        const LevelGeom g = P.lv[l];
-        const int comp_lo = B[l * 4 + 0], comp_n = B[l * 4 + 1], own_n = B[l * 4 + 3];
-        const int src_lo = B[(l - 1) * 4 + 0];
-        const int sh = P.lv[l - 1].h;
-        const int spitch = l == 1 ? P.pyr_p0 : P.lv[l - 1].pitch;
-        const uint8_t* src = smem_pyr + P.pyr_off[l - 1];      // LDS row 0 is level row src_lo
-        uint8_t* dl = smem_pyr + P.pyr_off[l];
-        uint8_t* dg = raw + (int64_t)frame * P.raw_frame_bytes + g.raw_off;
-        const uint32_t* xt = s_xt + (g.xtab - xt_lo);
-        const int groups = g.pitch >> 2;
-        const int items = comp_n * groups;
-        const float inv_groups = 1.0f / (float)groups;
-        for (int it = tid; it < items; it += 256) {
-            int r = (int)((float)it * inv_groups);
-            if (r * groups > it) r--;
-            else if ((r + 1) * groups <= it) r++;
-            const int gx = it - r * groups;
-            const int dy = comp_lo + r;
-            const int dx0 = gx * 4;
-            uint32_t outw = 0;
-            if (dx0 < g.w) {
-                const uint32_t ty = s_yt[r];
-                const int oy = ty & 0xFFFF, cy1 = (int)(ty >> 16);
-                uint32_t tx[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) tx[i] = xt[min(dx0 + i, g.w - 1)];
-                const int base = (int)(tx[0] & 0xFFFF) & ~3;
-                // 3 aligned dwords per source row cover the <= 9 source bytes four outputs need (scale ~1.2); a window
-                // may run past the row's end into the next LDS row: those bytes only ever meet weight 0
-                const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (oy - src_lo) * spitch + base);
-                const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (min(oy + 1, sh - 1) - src_lo) * spitch + base);
-                const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2];
-                const uint32_t b0 = q1[0], b1 = q1[1], b2 = q1[2];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int e = min((int)(tx[i] & 0xFFFF) - base, 7), cx1 = (int)(tx[i] >> 16);
-                    const uint32_t pa = window_pair(a0, a1, a2, e), pb = window_pair(b0, b1, b2, e);
-                    const int p00 = pa & 0xFF, p01 = (pa >> 8) & 0xFF, p10 = pb & 0xFF, p11 = (pb >> 8) & 0xFF;
-                    const int h0 = (p00 << 8) + cx1 * (p01 - p00);      // == (256-cx1)*p00 + cx1*p01
-                    const int h1 = (p10 << 8) + cx1 * (p11 - p10);
-                    const uint32_t v = (uint32_t)((h0 << 8) + cy1 * (h1 - h0) + 32768) >> 16;
-                    outw |= min(v, 255u) << (8 * i);
-                }
-            }
-            *reinterpret_cast<uint32_t*>(dl + r * g.pitch + dx0) = outw;
-            if (r < own_n) *reinterpret_cast<uint32_t*>(dg + (int64_t)dy * g.pitch + dx0) = outw;
-        }
-        __syncthreads();
-        if (l + 1 < kLevels) {       // y slice of the next level (the slice just used is dead after the barrier)
-            const int clo = B[(l + 1) * 4 + 0], cn = B[(l + 1) * 4 + 1];
-            if (tid < cn) s_yt[tid] = tab[P.lv[l + 1].ytab + clo + tid];
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// a6.2 + a6.7  one 64x32 tile of one level of one frame per workgroup.
-// ------------------------------------------------------------------------------------------------------
-// ring of radius 3 in circular order (fast_score.cpp makeOffsets); only circular adjacency matters
-#define RING_DX {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
-#define RING_DY {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
-
-// FAST-9/16 test + cornerScore<16> at LDS patch position c (row pitch kPatchW). Returns 0 if not a corner,
-// else the score (>= threshold). fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>.
-__device__ __forceinline__ int fast9_score(const uint8_t* c, int t) {
-    constexpr int dxs[16] = RING_DX;
-    constexpr int dys[16] = RING_DY;
-    const int v = c[0];
-    const int lo = v - t, hi = v + t;
-    // any 9 consecutive ring positions contain at least two of the compass points 0,4,8,12
-    int p0 = c[dys[0] * kPatchW + dxs[0]], p4 = c[dys[4] * kPatchW + dxs[4]];
-    int p8 = c[dys[8] * kPatchW + dxs[8]], p12 = c[dys[12] * kPatchW + dxs[12]];
-    int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
-    int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
-    if (nd < 2 && nb < 2) return 0;
-    int d[16];
-    uint32_t dark = 0, bright = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int p = c[dys[k] * kPatchW + dxs[k]];
-        d[k] = v - p;
-        dark |= (uint32_t)(p < lo) << k;
-        bright |= (uint32_t)(p > hi) << k;
-    }
-    uint32_t m = dark | (dark << 16);
-    uint32_t a = m & (m >> 1);
-    a &= a >> 2;
-    a &= a >> 4;
-    a &= m >> 8;
-    uint32_t mb = bright | (bright << 16);
-    uint32_t b = mb & (mb >> 1);
-    b &= b >> 2;
-    b &= b >> 4;
-    b &= mb >> 8;
-    if (((a | b) & 0xFFFFu) == 0) return 0;
-    // score = max over the 16 nine-arcs of min(d) and of min(-d), minus 1
-    int mn2[16], mx2[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-    int q0 = -1000, q1 = 1000;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        q0 = max(q0, mn9);
-        q1 = min(q1, mx9);
-    }
-    return max(q0, -q1) - 1;
-}
-
-__global__ __launch_bounds__(256) void k_fast_blur(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
-                                                   uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
-                                                   int* __restrict__ cand_cnt, int* __restrict__ err) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_pix[kPatchH * kPatchW];
-    __shared__ uint8_t s_score[(kTileH + 2) * (kTileW + 4)];
-    __shared__ uint16_t s_row[(kTileH + 6) * kTileW];
-
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.y;
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < kLevels; i++)
-        if ((int)blockIdx.x >= P.lv[i].tile_base) l = i;
-    const LevelGeom g = P.lv[l];
-    const int t_in = blockIdx.x - g.tile_base;
-    const int tyi = t_in / g.tiles_x, txi = t_in - tyi * g.tiles_x;
-    const int x0 = txi * kTileW, y0 = tyi * kTileH;
-    int pitch;
-    const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
-    const bool can_dword = (l > 0) || S.aligned4;
-
-    // ---- stage the (64+8) x (32+8) patch in LDS, BORDER_REFLECT_101 outside the level ----
-    for (int i = tid; i < kPatchH * (kPatchW / 4); i += 256) {
-        const int r = i / (kPatchW / 4), dcol = i - r * (kPatchW / 4);
-        const int gy = reflect101(y0 - kHalo + r, g.h);
-        const int gx = x0 - kHalo + dcol * 4;
-        const uint8_t* rowp = img + (int64_t)gy * pitch;
-        uint32_t w;
-        if (can_dword && gx >= 0 && gx + 3 < g.w) {
-            w = *reinterpret_cast<const uint32_t*>(rowp + gx);
-        } else {
-            w = (uint32_t)rowp[reflect101(gx, g.w)] | ((uint32_t)rowp[reflect101(gx + 1, g.w)] << 8) |
-                ((uint32_t)rowp[reflect101(gx + 2, g.w)] << 16) | ((uint32_t)rowp[reflect101(gx + 3, g.w)] << 24);
-        }
-        *reinterpret_cast<uint32_t*>(&s_pix[r * kPatchW + dcol * 4]) = w;
-    }
-    __syncthreads();
-
-    // ---- FAST score on the tile + 1 ring; only where a kept corner or its NMS neighbour can be ----
-    // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); clears all if the level is <= 62
-    const bool level_has_kp = (g.w > 2 * kEdgeThreshold) && (g.h > 2 * kEdgeThreshold);
-    const int t = P.fast_threshold;
-    constexpr int SW = kTileW + 4;  // score row pitch
-    for (int i = tid; i < (kTileH + 2) * (kTileW + 2); i += 256) {
-        const int sy = i / (kTileW + 2), sx = i - sy * (kTileW + 2);
-        const int X = x0 - 1 + sx, Y = y0 - 1 + sy;
-        int sc = 0;
-        if (level_has_kp && X >= kEdgeThreshold - 1 && X <= g.w - kEdgeThreshold && Y >= kEdgeThreshold - 1 &&
-            Y <= g.h - kEdgeThreshold)
-            sc = fast9_score(&s_pix[(sy + kHalo - 1) * kPatchW + (sx + kHalo - 1)], t);
-        s_score[sy * SW + sx] = (uint8_t)sc;
-    }
-    __syncthreads();
-
-    // ---- 3x3 strict-max NMS + border filter + wave-aggregated append (ballot / popcount prefix) ----
-    uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
-    int* ccnt = cand_cnt + frame * kLevels + l;
-    const int lane = tid & 63;
-    for (int i = tid; i < kTileH * kTileW; i += 256) {
-        const int py = i >> 6, px = i & 63;
-        const int X = x0 + px, Y = y0 + py;
-        bool keep = false;
-        int sc = 0;
-        if (level_has_kp && X >= kEdgeThreshold && X < g.w - kEdgeThreshold && Y >= kEdgeThreshold &&
-            Y < g.h - kEdgeThreshold) {
-            const uint8_t* s = &s_score[(py + 1) * SW + (px + 1)];
-            sc = s[0];
-            keep = sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-SW - 1] && sc > s[-SW] && sc > s[-SW + 1] &&
-                   sc > s[SW - 1] && sc > s[SW] && sc > s[SW + 1];
-        }
-        const unsigned long long mask = __ballot(keep);
-        if (mask) {
-            const int leader = __ffsll((long long)mask) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(ccnt, __popcll(mask));
-            base = __shfl(base, leader);
-            const int off = __popcll(mask & ((1ull << lane) - 1ull));
-            if (keep) {
-                if (base + off < g.cand_cap)
-                    clist[base + off] = (uint32_t)X | ((uint32_t)Y << 11) | ((uint32_t)sc << 22);
-                else
-                    atomicOr(err, ERRBIT_CAND_OVERFLOW);
-            }
-        }
-    }
-
-    // ---- 7x7 Gaussian, integer kernel {18,34,49,55,49,34,18} per pass (sum 257, not renormalised) ----
-    // row pass: rows y0-3 .. y0+34 of the level = patch rows 1..38
-    for (int i = tid; i < (kTileH + 6) * kTileW; i += 256) {
-        const int r = i >> 6, cx = i & 63;
-        const uint8_t* p = &s_pix[(r + 1) * kPatchW + cx + kHalo];
-        const int s = 18 * (p[-3] + p[3]) + 34 * (p[-2] + p[2]) + 49 * (p[-1] + p[1]) + 55 * p[0];
-        s_row[r * kTileW + cx] = (uint16_t)s;   // <= 255*257 = 65535
-    }
-    __syncthreads();
-    uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
-    const int body = g.w & ~3;   // SymmColumnVec_32s8u covers x < (w & ~3) with ties-to-even
-    for (int i = tid; i < kTileH * (kTileW / 4); i += 256) {
-        const int py = i >> 4, qx = (i & 15) * 4;
-        const int X = x0 + qx, Y = y0 + py;
-        if (Y >= g.h || X >= g.w) continue;
-        uint32_t outw = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint16_t* c = &s_row[py * kTileW + qx + j];
-            const int s = 18 * (c[0] + c[6 * kTileW]) + 34 * (c[kTileW] + c[5 * kTileW]) +
-                          49 * (c[2 * kTileW] + c[4 * kTileW]) + 55 * c[3 * kTileW];
-            int q = s >> 16;
-            const int rem = s & 0xFFFF;
-            if (rem > 32768) q += 1;
-            else if (rem == 32768) q += (P.tie_mode == 1 && (X + j) < body) ? (q & 1) : 1;
-            outw |= (uint32_t)min(q, 255) << (8 * j);
-        }
-        *reinterpret_cast<uint32_t*>(bl + (int64_t)Y * g.pitch + X) = outw;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------
 // a6.3-a6.5  one workgroup per (frame, level)
@@ -680,11 +143,18 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
     return ((float)a * (float)b - (float)c * (float)c - k * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
 }
 
+__device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
+                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                int* __restrict__ ovf, unsigned long long* __restrict__ keys, long long keys_cap,
+                                uint4* __restrict__ osel, int osel_cap, int frame, int l, int* s_hist);
+
 __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint4* __restrict__ sel, int* __restrict__ sel_cnt,
                                                 int* __restrict__ err, unsigned long long* __restrict__ stamps,
-                                                int* __restrict__ ovf, int2* __restrict__ ovf_items) {
+                                                int* __restrict__ ovf, unsigned long long* __restrict__ ovf_keys,
+                                                long long ovf_keys_cap, uint4* __restrict__ osel, int osel_cap) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     SSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
@@ -794,13 +264,8 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     int n1 = s_misc[1];
     if (n1 > kSortCap) {
         // more candidates tie at the FAST cut than the LDS sort holds (a tie storm: checkerboards, synthetic patterns).
-        // OpenCV's retainBest keeps them all, so this (frame, level) is redone by k_select_ovf in global memory.
-        if (tid == 0) {
-            sel_cnt[frame * kLevels + l] = 0;
-            const int it = atomicAdd(&ovf[0], 1);
-            if (it < kOvfItems) ovf_items[it] = make_int2(frame, l);
-            else atomicOr(err, ERRBIT_SORT_OVERFLOW);
-        }
+        // OpenCV's retainBest keeps them all, so this (frame, level) is redone in global memory.
+        select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l, s_hist);
         return;
     }
     int np = 1;
@@ -863,12 +328,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         n2 = q + s_misc[2];
     }
     if (n2 > g.sel_cap) {      // more ties at the Harris cut than the level's slots hold: same fallback
-        if (tid == 0) {
-            sel_cnt[frame * kLevels + l] = 0;
-            const int it = atomicAdd(&ovf[0], 1);
-            if (it < kOvfItems) ovf_items[it] = make_int2(frame, l);
-            else atomicOr(err, ERRBIT_SEL_OVERFLOW);
-        }
+        select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l, s_hist);
         return;
     }
     // Emit in raster order of 32 x 32-px tiles (counting sort, order inside a tile arbitrary), each record carrying its rank i in
@@ -939,18 +399,16 @@ __device__ __forceinline__ void ovf_st(unsigned long long* p, unsigned long long
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
-                                                    const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
-                                                    uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
-                                                    int* __restrict__ ovf, const int2* __restrict__ ovf_items,
-                                                    unsigned long long* __restrict__ keys, long long keys_cap,
-                                                    uint4* __restrict__ osel, int osel_cap) {
-    __shared__ int s_hist[256];
-    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena base (-1: none), [4] osel base
+// One (frame, level) through the global-memory selection; called by the workgroup of k_select that found the ties
+// overflowing its LDS capacities (all 256 threads, uniformly).
+__device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
+                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                int* __restrict__ ovf, unsigned long long* __restrict__ keys, long long keys_cap,
+                                uint4* __restrict__ osel, int osel_cap, int frame, int l, int* s_hist) {
+    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena ok, [4] osel base, [5] n1, [6..7] key base
     const int tid = threadIdx.x;
-    const int n_items = min(ovf[0], kOvfItems);
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int frame = ovf_items[it].x, l = ovf_items[it].y;
+    {
         const LevelGeom g = P.lv[l];
         const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
         const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
@@ -980,7 +438,7 @@ __global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const ui
             s_misc[5] = n1;
         }
         __syncthreads();
-        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; continue; }
+        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; return; }
         const int thr = s_misc[0], n1 = s_misc[5];
         unsigned long long* K = keys + reinterpret_cast<long long*>(s_misc + 6)[0];
         long long np = 1;
@@ -1158,7 +616,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err, int n_frames, int blocks_per_frame,
                                                   unsigned long long* __restrict__ stamps,
-                                                  const uint4* __restrict__ osel, const int* __restrict__ ovf, int osel_cap) {
+                                                  const uint4* __restrict__ osel, const int* __restrict__ ovf, int osel_cap,
+                                                  int n_regular) {
     // diagnostic only (ARIA_DESC_STAMPS=1): s_memtime at the phase boundaries of every wave
 #define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * kDescWaves + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     DSTAMP(0);
@@ -1168,12 +627,15 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     uint8_t (*s_raw)[kDescRows * kDescPitch] = s_patch;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
-    // regular pass: one trip (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks
-    const int n_blk = osel ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : (int)gridDim.x;
-    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    // blocks 0 .. n_regular-1: one trip each over the frames' regular slots; the few blocks after them stride over the
+    // tie-storm arena (empty on ordinary images: they read one counter and leave)
+    const bool arena = (int)blockIdx.x >= n_regular;
+    const int n_blk = arena ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : n_regular;
+    const int blk_step = arena ? (int)gridDim.x - n_regular : (int)gridDim.x;
+    for (int blk = arena ? (int)blockIdx.x - n_regular : (int)blockIdx.x; blk < n_blk; blk += blk_step) {
     int frame, l = 0, base = 0, nk;
     uint4 sv;
-    if (osel == nullptr) {
+    if (!arena) {
         // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
         // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
         const int xcd = blk & 7, j = blk >> 3;
@@ -1468,7 +930,7 @@ int LaunchCtx::init(int dev) {
     // so every handle sets it for its own device
     ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(sizeof(unsigned long long) * kSortCapMax)));
-    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    if (int prc = pyramid_set_attributes(); prc != ARIA_OK) return prc;
     int rc = band_set_attributes();
     if (rc != ARIA_OK) return rc;
     rc = band2_set_attributes();
@@ -1484,7 +946,8 @@ void LaunchCtx::release() {
     for (int l = 0; l < kLevels; l++) {
         if (side[l]) hipStreamDestroy(side[l]);
         if (ev_join[l]) hipEventDestroy(ev_join[l]);
-        side[l] = nullptr; ev_join[l] = nullptr;
+        if (ev_lvl[l]) hipEventDestroy(ev_lvl[l]);
+        side[l] = nullptr; ev_join[l] = nullptr; ev_lvl[l] = nullptr;
     }
     if (ev_fork) hipEventDestroy(ev_fork);
     ev_fork = nullptr;
@@ -1497,47 +960,22 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
                           Profiler* prof, LaunchCtx& ctx) {
     const EnvConfig& E = env_config();
     if (prof && prof->enabled) prof->frames += n_frames;
-    hipMemsetAsync(D.cand_cnt, 0, sizeof(int) * kLevels * (size_t)n_frames, st);
-    hipMemsetAsync(D.ovf, 0, 4 * sizeof(int), st);
+    hipMemsetAsync(D.ovf, 0, sizeof(int) * (4 + kLevels * (size_t)n_frames), st);    // arena counters + candidate counters (adjacent)
 
     // ---- a6.1 pyramid ----
     // Default: no pass of its own -- the FAST/blur launch of level l writes the raw rows of level l+1 from the rows it
     // has staged (fast_blur_band.hip). A separate pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL,
     // ARIA_PYRAMID_IMPL) or when the band kernel is not the one in use (tile kernel, per-level side streams).
-    const bool fuse_resize = E.fuse_resize != 0;
-    if (!fuse_resize) {
-    if (prof) prof->begin(STAGE_RESIZE, st);
-    const int pyr_impl = E.pyr_impl;   // 0 = one resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
-                                       // measured slower at 640x480: the top-down halo makes small bands recompute too much)
-    if (pyr_impl == 1 && P.pyr_lds_bytes <= 150 * 1024) {
-        ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S,
-                    D.raw, D.tab, D.pyr_bands);
+    const bool latency = ctx.schedule == 1 && ctx.ev_fork != nullptr && E.fast_blur_impl == 2 && !(prof && prof->enabled);
+    const bool fuse_resize = E.fuse_resize != 0 && !latency;
+    if (latency) {
+        // single-frame latency schedule: resize chain and the 8 FAST/blur launches overlap (fast_blur_band.hip)
+        launch_pyramid_and_band_latency(P, S, D, n_frames, st, prof, ctx);
     } else {
-        // 2 = LDS-staged bands with dot2 arithmetic (default), 1 = LDS-staged bands with shift/mad arithmetic
-        // (ARIA_RESIZE_IMPL=lds), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)
-        const int rs_impl = E.rs_impl;
-        for (int l = 1; l < kLevels; l++) {
-            if (rs_impl >= 1) {
-                const int lp = (P.lv[l - 1].w + 15) / 16 * 16 + 16;
-                const size_t xt_words = rs_impl == 2 ? 3 * (size_t)((P.lv[l].w + 3) & ~3) : (size_t)P.lv[l].w;
-                const size_t lds = (size_t)((kResizeBand * 13) / 10 + 4) * lp + sizeof(uint32_t) * (xt_words + kResizeBand) + 16;
-                if (lds <= 64 * 1024) {
-                    const dim3 grid((P.lv[l].h + kResizeBand - 1) / kResizeBand, n_frames);
-                    if (rs_impl == 2) ARIA_LAUNCH(prof, k_resize_lds<true>, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
-                    else ARIA_LAUNCH(prof, k_resize_lds<false>, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
-                    continue;
-                }
-            }
-            const int items = (P.lv[l].pitch >> 2) * ((P.lv[l].h + kResizeRows - 1) / kResizeRows);
-            dim3 grid((items + 255) / 256, n_frames);
-            // LDS: the level's x table + the y entries of the row-chunks a block can touch (256 items span <= 256/groups + 2 chunks)
-            const int groups = P.lv[l].pitch >> 2;
-            const size_t lds = sizeof(uint32_t) * ((size_t)P.lv[l].w + (size_t)kResizeRows * (256 / groups + 2));
-            ARIA_LAUNCH(prof, k_resize, grid, dim3(256), lds, st, P, S, D.raw, D.tab, l);
-        }
-    }
-
-    if (prof) prof->end(st);
+    if (!fuse_resize) {
+        if (prof) prof->begin(STAGE_RESIZE, st);
+        launch_pyramid_pass(P, S, D, n_frames, st, prof);
+        if (prof) prof->end(st);
     }
 
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
@@ -1547,11 +985,10 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     } else if (E.fast_blur_impl != 0) {
         launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     } else {
-        ARIA_LAUNCH(prof, k_fast_blur, dim3(P.total_tiles, n_frames), dim3(256), 0, st, P, S, D.raw, D.blur,
-                    D.cand, D.cand_cnt, D.err);
+        launch_fast_blur_tile(P, S, D, n_frames, st, prof);
     }
-
     if (prof) prof->end(st);
+    }
 
     // ---- a6.3-a6.5 selection ----
     if (prof) prof->begin(STAGE_SELECT, st);
@@ -1559,10 +996,8 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;
     if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
     ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
-                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items);
-    // tie-storm fallback: a fixed small grid that finds the work list empty on ordinary images
-    ARIA_LAUNCH(prof, k_select_ovf, dim3(64), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err,
-                D.ovf, D.ovf_items, D.ovf_keys, D.ovf_keys_cap, D.osel, D.osel_cap);
+                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_keys, D.ovf_keys_cap, D.osel,
+                D.osel_cap);
     if (sstp) {
         hipStreamSynchronize(st);
         std::vector<unsigned long long> hs((size_t)n_frames * kLevels * 8);
@@ -1591,13 +1026,10 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
         unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
-        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
-                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
-                    (const int*)nullptr, 0);
-        // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
-        ARIA_LAUNCH(prof, k_describe, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
-                    D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
-                    (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
+        constexpr int kArenaBlocks = 64;   // blocks behind the regular ones that stride over the tie-storm arena
+        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8 + kArenaBlocks)), dim3(64 * kDescWaves), 0, st, P, S, D.raw,
+                    D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)D.osel,
+                    (const int*)D.ovf, D.osel_cap, bpf * frames8);
         if (stp) {
             hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(nwaves * 8);
