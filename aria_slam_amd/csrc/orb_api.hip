@@ -83,7 +83,7 @@ void free_scratch(aria_orb_s* h) {
     drop_graph(h);              // the captured sequence points into the buffers freed below
     hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand);     // (D.cand_cnt lives behind D.ovf)
     hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.pyr_bands);    // (D.err lives inside d_out)
-    hipFree(h->D.ovf); hipFree(h->D.ovf_keys); hipFree(h->D.osel);
+    hipFree(h->D.ovf); hipFree(h->D.ovf_items); hipFree(h->D.ovf_keys); hipFree(h->D.osel);
     hipFree(h->d_img); hipFree(h->d_out);
     if (h->h_img) hipHostFree(h->h_img);
     if (h->h_out) hipHostFree(h->h_out);
@@ -135,6 +135,7 @@ int alloc_scratch(aria_orb_s* h) {
         for (int l = 0; l < kLevels; l++) { long long np = 1; while (np < mp.lv[l].cand_cap) np <<= 1; per_frame += np; }
         h->D.ovf_keys_cap = 4 * per_frame;
         h->D.osel_cap = (int)std::min<long long>(4 * (long long)mp.cand_frame_entries + 64, 1ll << 24);
+        ARIA_HIP(hipMalloc(&h->D.ovf_items, sizeof(int2) * kOvfItems));
         ARIA_HIP(hipMalloc(&h->D.ovf_keys, sizeof(unsigned long long) * (size_t)h->D.ovf_keys_cap));
         ARIA_HIP(hipMalloc(&h->D.osel, sizeof(uint4) * (size_t)h->D.osel_cap));
     }

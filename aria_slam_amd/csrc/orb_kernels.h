@@ -34,7 +34,8 @@ struct DeviceScratch {
     int* err;            // deferred error bits
     // tie-storm fallback (select_ovf_item): a key arena for the global-memory sort of (frame, level) pairs whose ties
     // overflow k_select's LDS capacities, and an arena of selected keypoints beyond a level's regular slots
-    int* ovf;            // [1] osel entries used, [2..3] key-arena entries used (64-bit)
+    int* ovf;            // [0] work-list items, [1] osel entries used, [2..3] key-arena entries used (64-bit)
+    int2* ovf_items;     // [kOvfItems] (frame, level) pairs k_select hands to k_select_ovf
     unsigned long long* ovf_keys;
     long long ovf_keys_cap;
     uint4* osel;

@@ -143,18 +143,11 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
     return ((float)a * (float)b - (float)c * (float)c - k * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
 }
 
-__device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
-                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
-                                uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
-                                int* __restrict__ ovf, unsigned long long* __restrict__ keys, long long keys_cap,
-                                uint4* __restrict__ osel, int osel_cap, int frame, int l, int* s_hist);
-
 __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint4* __restrict__ sel, int* __restrict__ sel_cnt,
                                                 int* __restrict__ err, unsigned long long* __restrict__ stamps,
-                                                int* __restrict__ ovf, unsigned long long* __restrict__ ovf_keys,
-                                                long long ovf_keys_cap, uint4* __restrict__ osel, int osel_cap) {
+                                                int* __restrict__ ovf, int2* __restrict__ ovf_items) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     SSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
@@ -264,8 +257,13 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     int n1 = s_misc[1];
     if (n1 > kSortCap) {
         // more candidates tie at the FAST cut than the LDS sort holds (a tie storm: checkerboards, synthetic patterns).
-        // OpenCV's retainBest keeps them all, so this (frame, level) is redone in global memory.
-        select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l, s_hist);
+        // OpenCV's retainBest keeps them all, so this (frame, level) is redone by k_select_ovf in global memory.
+        if (tid == 0) {
+            sel_cnt[frame * kLevels + l] = 0;
+            const int it = atomicAdd(&ovf[0], 1);
+            if (it < kOvfItems) ovf_items[it] = make_int2(frame, l);
+            else atomicOr(err, ERRBIT_SORT_OVERFLOW);
+        }
         return;
     }
     int np = 1;
@@ -328,7 +326,12 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         n2 = q + s_misc[2];
     }
     if (n2 > g.sel_cap) {      // more ties at the Harris cut than the level's slots hold: same fallback
-        select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l, s_hist);
+        if (tid == 0) {
+            sel_cnt[frame * kLevels + l] = 0;
+            const int it = atomicAdd(&ovf[0], 1);
+            if (it < kOvfItems) ovf_items[it] = make_int2(frame, l);
+            else atomicOr(err, ERRBIT_SEL_OVERFLOW);
+        }
         return;
     }
     // Emit in raster order of 32 x 32-px tiles (counting sort, order inside a tile arbitrary), each record carrying its rank i in
@@ -399,16 +402,18 @@ __device__ __forceinline__ void ovf_st(unsigned long long* p, unsigned long long
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One (frame, level) through the global-memory selection; called by the workgroup of k_select that found the ties
-// overflowing its LDS capacities (all 256 threads, uniformly).
-__device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
-                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
-                                uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
-                                int* __restrict__ ovf, unsigned long long* __restrict__ keys, long long keys_cap,
-                                uint4* __restrict__ osel, int osel_cap, int frame, int l, int* s_hist) {
-    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena ok, [4] osel base, [5] n1, [6..7] key base
+__global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                    const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                                    uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                                    int* __restrict__ ovf, const int2* __restrict__ ovf_items,
+                                                    unsigned long long* __restrict__ keys, long long keys_cap,
+                                                    uint4* __restrict__ osel, int osel_cap) {
+    __shared__ int s_hist[256];
+    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena base (-1: none), [4] osel base
     const int tid = threadIdx.x;
-    {
+    const int n_items = min(ovf[0], kOvfItems);
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int frame = ovf_items[it].x, l = ovf_items[it].y;
         const LevelGeom g = P.lv[l];
         const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
         const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
@@ -438,7 +443,7 @@ __device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t*
             s_misc[5] = n1;
         }
         __syncthreads();
-        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; return; }
+        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; continue; }
         const int thr = s_misc[0], n1 = s_misc[5];
         unsigned long long* K = keys + reinterpret_cast<long long*>(s_misc + 6)[0];
         long long np = 1;
@@ -616,8 +621,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
                                                   int* __restrict__ err, int n_frames, int blocks_per_frame,
                                                   unsigned long long* __restrict__ stamps,
-                                                  const uint4* __restrict__ osel, const int* __restrict__ ovf, int osel_cap,
-                                                  int n_regular) {
+                                                  const uint4* __restrict__ osel, const int* __restrict__ ovf, int osel_cap) {
     // diagnostic only (ARIA_DESC_STAMPS=1): s_memtime at the phase boundaries of every wave
 #define DSTAMP(k) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((size_t)blockIdx.x * kDescWaves + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     DSTAMP(0);
@@ -627,15 +631,12 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     uint8_t (*s_raw)[kDescRows * kDescPitch] = s_patch;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
-    // blocks 0 .. n_regular-1: one trip each over the frames' regular slots; the few blocks after them stride over the
-    // tie-storm arena (empty on ordinary images: they read one counter and leave)
-    const bool arena = (int)blockIdx.x >= n_regular;
-    const int n_blk = arena ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : n_regular;
-    const int blk_step = arena ? (int)gridDim.x - n_regular : (int)gridDim.x;
-    for (int blk = arena ? (int)blockIdx.x - n_regular : (int)blockIdx.x; blk < n_blk; blk += blk_step) {
+    // regular pass: one trip (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks
+    const int n_blk = osel ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : (int)gridDim.x;
+    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
     int frame, l = 0, base = 0, nk;
     uint4 sv;
-    if (!arena) {
+    if (osel == nullptr) {
         // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
         // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
         const int xcd = blk & 7, j = blk >> 3;
@@ -996,8 +997,10 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;
     if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
     ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
-                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_keys, D.ovf_keys_cap, D.osel,
-                D.osel_cap);
+                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items);
+    // tie-storm fallback: a fixed small grid that finds the work list empty on ordinary images
+    ARIA_LAUNCH(prof, k_select_ovf, dim3(64), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err,
+                D.ovf, D.ovf_items, D.ovf_keys, D.ovf_keys_cap, D.osel, D.osel_cap);
     if (sstp) {
         hipStreamSynchronize(st);
         std::vector<unsigned long long> hs((size_t)n_frames * kLevels * 8);
@@ -1026,10 +1029,13 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
         unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
-        constexpr int kArenaBlocks = 64;   // blocks behind the regular ones that stride over the tie-storm arena
-        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8 + kArenaBlocks)), dim3(64 * kDescWaves), 0, st, P, S, D.raw,
-                    D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)D.osel,
-                    (const int*)D.ovf, D.osel_cap, bpf * frames8);
+        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
+                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
+                    (const int*)nullptr, 0);
+        // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
+        ARIA_LAUNCH(prof, k_describe, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
+                    D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
+                    (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
         if (stp) {
             hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(nwaves * 8);

@@ -23,6 +23,7 @@ constexpr int kPatchH = kTileH + 2 * kHalo;  // 40
 constexpr int kSortCapMin = 4096;    // LDS bitonic sort capacity of the per-(frame,level) selection kernel (entries of 8 B)
 constexpr int kSortCapMax = 16384;   // 128 KB of the CU's 160 KB LDS
 constexpr int kSelSlack = 64;    // extra output slots per level for ties at the Harris cut
+constexpr int kOvfItems = 4096;  // (frame, level) pairs per pass whose ties overflow the LDS selection (k_select_ovf's work list)
 constexpr int kPyrYSlice = 96;   // max rows a pyramid band computes per level
 constexpr int kMaxDim = 2047;    // candidate packing: x:11 | y:11 | score:8
 
