@@ -228,17 +228,18 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
         const uint32_t T2 = (uint32_t)thr * 0x00010001u;
         const int o_min = sb == 0 ? -1 : 0, o_max = sb == nb - 1 ? kBandR : kBandR - 1;
         uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off + x;
-        const int body = w & ~3;   // SymmColumnVec_32s8u (ties to even) covers x < (w & ~3); the scalar tail rounds ties up
-        const bool tie_even_lane = TIE_EVEN && (x < body);
-        const uint32_t rnd_bias = tie_even_lane ? 0x7FFFu : 0x8000u, rnd_odd = tie_even_lane ? 1u : 0u;
 
         const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
         const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
 
         // 7-row register window; slot = step % 7 (static after unrolling by 7)
         uint32_t RS[7][4], RC2[7][2], RE[7], RW[7];
+        float RF[7][4];       // the row sums as floats (blur_tie_mode 1: the column pass runs in fp32, see below)
 #pragma unroll
-        for (int u = 0; u < 7; u++) { RC2[u][0] = RC2[u][1] = RE[u] = RW[u] = 0; RS[u][0] = RS[u][1] = RS[u][2] = RS[u][3] = 0; }
+        for (int u = 0; u < 7; u++) {
+            RC2[u][0] = RC2[u][1] = RE[u] = RW[u] = 0; RS[u][0] = RS[u][1] = RS[u][2] = RS[u][3] = 0;
+            RF[u][0] = RF[u][1] = RF[u][2] = RF[u][3] = 0.f;
+        }
 
         const uint32_t* lrow = reinterpret_cast<const uint32_t*>(s_pix) + (sb * kBandR) * dpr + li;
         for (int tb = 0; tb < kStripRows; tb += 7) {
@@ -260,6 +261,10 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                     RS[u][2] = __builtin_amdgcn_udot4(RE[u], KHI,
                                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), KLO, 0u, false), false);
                     RS[u][3] = __builtin_amdgcn_udot4(w2, KHI, __builtin_amdgcn_udot4(w1, KLO, 0u, false), false);
+                    if (TIE_EVEN) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) RF[u][j] = (float)RS[u][j];      // exact: < 2^16
+                    }
 
                     const int o = t - 7;              // strip row whose window [o-3, o+3] is now complete
                     const int Y = yb + o;
@@ -269,6 +274,23 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                     if (o >= 0 && o < kBandR && Y < h) {
                         // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u)
                         uint32_t outw = 0;
+                        if (TIE_EVEN) {
+                            // blur_tie_mode 1: OpenCV's SymmColumnVec_32s8u rounds the column sums to nearest EVEN, which is
+                            // what v_cvt_pk_u8_f32 does (plus saturation and the byte insert) in one instruction. All values
+                            // are integers * 2^-16 below 2^9, so the fp32 column pass is exact (sums < 2^25: a partial sum
+                            // can only be inexact above 256.0, which saturates either way); 7 fast-rate float ops per pixel
+                            // instead of 3 adds + 4 24-bit multiplies + 4 integer rounding ops. The scalar-tail columns
+                            // (x >= w & ~3, ties round UP there) are redone in integers after the walk.
+                            constexpr float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                float acc = k0 * RF[sC][j];
+                                acc = __builtin_fmaf(k1, RF[sM1][j] + RF[sP1][j], acc);
+                                acc = __builtin_fmaf(k2, RF[sM2][j] + RF[sP2][j], acc);
+                                acc = __builtin_fmaf(k3, RF[sM3][j] + RF[sP3][j], acc);
+                                outw = __builtin_amdgcn_cvt_pk_u8_f32(acc, j, outw);
+                            }
+                        } else {
                         constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of r -> byte j
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
@@ -277,9 +299,10 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                             acc = umad24(49u, RS[sM1][j] + RS[sP1][j], acc);
                             acc = umad24(34u, RS[sM2][j] + RS[sP2][j], acc);
                             acc = umad24(18u, RS[sM3][j] + RS[sP3][j], acc);
-                            // round by 2^16: ties to even = + 0x7FFF + (quotient odd), ties up = + 0x8000; saturate to 255
-                            const uint32_t r = acc + rnd_bias + ((acc >> 16) & rnd_odd);
+                            // ties up: + 0x8000, quotient by 2^16, saturate to 255
+                            const uint32_t r = acc + 0x8000u;
                             outw = __builtin_amdgcn_perm(min(r, 0x00FFFFFFu), outw, put[j]);
+                        }
                         }
                         *reinterpret_cast<uint32_t*>(bl + (int64_t)Y * g.pitch) = outw;
                     }
@@ -389,8 +412,30 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
         }
     }
     STAMP(2);
-    __syncthreads();
+    __syncthreads();     // (also waits for this wave's blurred-row stores: the fix-up below overwrites bytes of them)
     STAMP(3);
+
+    // ---- blur_tie_mode 1: OpenCV's SIMD column filter covers x < (w & ~3) (ties to even: what the fp32 column pass above
+    //      computed); its scalar tail, the last w mod 4 columns, rounds ties UP. Those <= 3 columns per row are recomputed
+    //      here in integers from the staged pixels (filter.simd.hpp SymmColumnFilter) and overwrite the bytes stored above. ----
+    if (TIE_EVEN && (w & 3) && !(ablate & 2)) {
+        const int nt = w & 3, xb = w & ~3;
+        uint8_t* blf = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
+        for (int i = tid; i < RB * nt; i += nthr) {
+            const int ro = i / nt, xx = xb + (i - ro * nt);
+            const int Y = y0 + ro;
+            if (Y >= h) continue;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int dy = 0; dy < 7; dy++) {
+                const uint8_t* p = s_pix + (ro + 1 + dy) * pitchL + (xx + 4);
+                const uint32_t hs = 18u * (p[-3] + p[3]) + 34u * (p[-2] + p[2]) + 49u * (p[-1] + p[1]) + 55u * p[0];
+                const uint32_t kv = dy == 0 || dy == 6 ? 18u : dy == 1 || dy == 5 ? 34u : dy == 2 || dy == 4 ? 49u : 55u;
+                acc += kv * hs;
+            }
+            blf[(int64_t)Y * g.pitch + xx] = (uint8_t)min((acc + 0x8000u) >> 16, 255u);
+        }
+    }
 
     uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
     int* ccnt = cand_cnt + frame * kLevels + l;

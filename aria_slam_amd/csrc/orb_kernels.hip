@@ -615,6 +615,7 @@ __device__ __forceinline__ int row16_sum(int v) {
 //   IC moments : columns u = 2*l16-15, 2*l16-14 over the 31 rows of the disc, DPP row reduction
 //   rBRIEF     : test 16*it + l16 for it = 0..15; one 64-bit ballot per iteration carries 16 descriptor bits for each
 //                of the four keypoints; lane l16 keeps word l16 and stores its two bytes
+template <bool ARENA>
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint4* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
@@ -632,11 +633,12 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
     // regular pass: one trip (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks
-    const int n_blk = osel ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : (int)gridDim.x;
+    // (ARENA is a template parameter: the regular pass compiles to straight-line code, exactly one trip)
+    const int n_blk = ARENA ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : (int)blockIdx.x + 1;
     for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
     int frame, l = 0, base = 0, nk;
     uint4 sv;
-    if (osel == nullptr) {
+    if (!ARENA) {
         // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
         // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
         const int xcd = blk & 7, j = blk >> 3;
@@ -1029,11 +1031,11 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
         unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
-        ARIA_LAUNCH(prof, k_describe, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
+        ARIA_LAUNCH(prof, k_describe<false>, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
                     D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
                     (const int*)nullptr, 0);
         // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
-        ARIA_LAUNCH(prof, k_describe, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
+        ARIA_LAUNCH(prof, k_describe<true>, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
                     D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
                     (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
         if (stp) {

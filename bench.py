@@ -232,6 +232,53 @@ def verify_last_step(A, torch, dev, images, last, halo_img, B, W, H, NF, cap, ra
     return res
 
 
+def single_frame_latency(A, dev, images, W, H, NF, n=48):
+    """What a frame-at-a-time caller of IFeatureExtractor::extract / IMatcher::match sees (one frame in flight, pageable host
+    buffers in and out, PCIe both ways, sync per call): the host entry points replay a hipGraph of a latency schedule.
+    Never `value`: reported beside it."""
+    import ctypes as C
+    n = min(n, images.shape[0])
+    seq = images[:n].cpu().numpy()
+    e = A.OrbHipExtractor(max_features=NF, device=dev.index, max_width=W, max_height=H)
+    m = A.HipMatcher(device=dev.index)
+    try:
+        L = e._L
+        cap = e.kp_capacity()
+        kp = [np.empty(cap, A.KP_DTYPE) for _ in range(2)]
+        ds = [np.empty((cap, 32), np.uint8) for _ in range(2)]
+        mt = np.empty(cap, A.MATCH_DTYPE)
+        cnt = [C.c_int(), C.c_int()]
+        nm = C.c_int()
+
+        def ext(i, slot):
+            rc = L.aria_orb_extract(e._h, seq[i].ctypes.data, W, H, W, kp[slot].ctypes.data, ds[slot].ctypes.data, cap, C.byref(cnt[slot]))
+            assert rc == 0, rc
+        for i in range(min(8, n)):
+            ext(i, 0)
+        reps = 4
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for i in range(n):
+                ext(i, 0)
+        t1 = time.perf_counter()
+        ext(0, 1)
+        for _ in range(reps):
+            for i in range(n):
+                s = i & 1
+                ext(i, s)
+                rc = L.aria_matcher_match(m._h, ds[s].ctypes.data, cnt[s].value, ds[1 - s].ctypes.data, cnt[1 - s].value,
+                                          C.c_float(0.75), mt.ctypes.data, cap, C.byref(nm))
+                assert rc == 0, rc
+        t2 = time.perf_counter()
+        return {"what": "aria_orb_extract / + aria_matcher_match through host buffers, one frame in flight, sync per call "
+                        "(hipGraph replay of the single-frame latency schedule); PCIe-inclusive, never `value`",
+                "extract_us": round(1e6 * (t1 - t0) / (reps * n), 1),
+                "extract_plus_match_us": round(1e6 * (t2 - t1) / (reps * n), 1), "frames": reps * n}
+    finally:
+        e.close()
+        m.close()
+
+
 def loop_closure_leg(A, torch, dist, dev, mat, last, B, cap, rank, world, rehearsal, lo_frame):
     """BASELINE.json configs[4]'s exchange, once, untimed by the headline clock: every rank turns evenly spaced frames
     of its shard into keyframes (500 node-wide, the reference's database cap, src/legacy/LoopClosure.cpp:28-30),
@@ -289,6 +336,10 @@ def main():
     ap.add_argument("--no-loop-closure", action="store_true", help="skip the untimed keyframe-DB exchange + scan leg")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="extractor and matcher on one stream (default: matcher of step s beside the extractor of step s+1)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="extractor lanes: the per-GPU sequence is cut into this many contiguous parts, each with its own "
+                         "extractor handle and stream, so that the VALU-bound FAST/blur launches of one part run beside the "
+                         "memory-bound select/describe launches of another (chunk-level pipelining; results unchanged)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -387,8 +438,15 @@ def main():
     sm = torch.cuda.Stream(device=dev) if args.pipeline else se
     torch.cuda.set_stream(se)
     assert se.cuda_stream != 0 and sm.cuda_stream != 0
+    lanes = max(1, min(args.lanes, B)) if args.pipeline else 1
+    lane_lo = [(B * k) // lanes for k in range(lanes + 1)]
+    lane_streams = [se] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+    if lanes > 1:
+        args.chunk = min(args.chunk, max(lane_lo[k + 1] - lane_lo[k] for k in range(lanes)))
     ext = A.OrbHipExtractor(max_features=NF, stream=se.cuda_stream, device=dev.index, max_width=W, max_height=H,
                             max_batch=args.chunk)
+    exts = [ext] + [A.OrbHipExtractor(max_features=NF, stream=lane_streams[k].cuda_stream, device=dev.index, max_width=W,
+                                      max_height=H, max_batch=args.chunk) for k in range(1, lanes)]
     mat = A.HipMatcher(stream=sm.cuda_stream, device=dev.index, max_query=4096, max_train=4096)
     cap = ext.kp_capacity()
     dstride = cap * 32
@@ -399,7 +457,7 @@ def main():
                          counts=torch.zeros((B,), dtype=torch.int32, device=dev),
                          matches=torch.empty((B, cap, 12), dtype=torch.uint8, device=dev),
                          nmatches=torch.zeros((B,), dtype=torch.int32, device=dev),
-                         described=torch.cuda.Event(), matched=torch.cuda.Event()))
+                         described=[torch.cuda.Event() for _ in range(lanes)], matched=torch.cuda.Event()))
     halo_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
     halo_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
     step_no = [0]
@@ -407,16 +465,26 @@ def main():
     def step(serialise=False):
         d = sets[step_no[0] % len(sets)]
         step_no[0] += 1
-        with torch.cuda.stream(se):
-            if args.pipeline:
-                se.wait_event(d["matched"])       # recorded two steps ago (a no-op before that)
-            ext.extract_batch_device(images, B, W, H, d["kps"], d["desc"], d["counts"], cap)
-            d["described"].record(se)
+        # lanes: the un-bracketed lanes are enqueued first -- the bracketed lane 0 blocks the host while its FAST/blur
+        # launches run, and the other lanes' work has to be in their queues by then
+        # (the extra, fully bracketed step runs the whole sequence through lane 0's handle alone)
+        for k in ([0] if serialise else list(range(1, lanes)) + [0]):
+            lo, n = (0, B) if serialise else (lane_lo[k], lane_lo[k + 1] - lane_lo[k])
+            sk = lane_streams[k]
+            with torch.cuda.stream(sk):
+                if args.pipeline:
+                    sk.wait_event(d["matched"])       # recorded two steps ago (a no-op before that)
+                exts[k].extract_batch_device(images.data_ptr() + lo * W * H, n, W, H, d["kps"].data_ptr() + lo * cap * 24,
+                                             d["desc"].data_ptr() + lo * cap * 32, d["counts"].data_ptr() + 4 * lo, cap)
+                d["described"][k].record(sk)
         if serialise:
             torch.cuda.synchronize(dev)
+            for ev in d["described"][1:]:
+                ev.record(se)
         with torch.cuda.stream(sm):
             if args.pipeline:
-                sm.wait_event(d["described"])
+                for ev in d["described"]:
+                    sm.wait_event(ev)
             mat.match_batch_device(d["desc"], d["counts"], halo_desc, halo_cnt, 1, dstride, args.ratio, d["matches"],
                                    d["nmatches"], cap)
             mat.match_batch_device(d["desc"].data_ptr() + dstride, d["counts"].data_ptr() + 4, d["desc"], d["counts"], B - 1,
@@ -442,7 +510,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ext.check()
+    for e_ in exts:
+        e_.check()
     mat.sync()
     # Timed region: HIP-event brackets only around what the roofline objects report (the dominant kernel and the
     # matcher's kNN-2); every bracket drains the stream twice. The full per-stage table comes from one extra,
@@ -461,14 +530,15 @@ def main():
         last = step()
     barrier()
     dt = time.perf_counter() - t0
-    ext.check()
+    for e_ in exts:
+        e_.check()
     mat.sync()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=("cpu" if rehearsal else dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    slow_blocks = ext.slow_path_blocks(reset=True)      # band-kernel workgroups that fell back to dense rescoring
+    slow_blocks = sum(e_.slow_path_blocks(reset=True) for e_ in exts)      # band-kernel workgroups that fell back to dense rescoring
     prof_e, prof_frames = ext.get_profile(reset=True)
     prof_m, prof_pairs = mat.get_profile(reset=True)
     ext.set_profiling(False)
@@ -493,6 +563,14 @@ def main():
             loop_closure = loop_closure_leg(A, torch, dist, dev, mat, last, B, cap, rank, world, rehearsal, lo_frame)
         except Exception as e:          # reported, never hidden; the headline number does not depend on it
             loop_closure = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- untimed: the frame-at-a-time host path (second, clearly labelled figure) ----
+    single = None
+    if rank == 0 and not args.no_verify and args.steps > 0:
+        try:
+            single = single_frame_latency(A, dev, images, W, H, NF)
+        except Exception as e:
+            single = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # extra untimed step with every stage bracketed, extractor and matcher one after the other -> stage_us_per_frame
     ext.set_profiling(True)
@@ -605,6 +683,7 @@ def main():
                        "rccl_ranks": rccl_ranks,
                        "streams": ("extractor and matcher on two streams, double-buffered outputs: the matcher of step s "
                                    "runs beside the extractor of step s+1") if args.pipeline else "one stream",
+                       "extractor_lanes": lanes,
                        "mean_keypoints_per_frame": round(float(cnt_host.mean()), 2),
                        "mean_matches_per_frame": round(float(nm_host.mean()), 2),
                        "slow_path_blocks": int(slow_blocks)},
@@ -618,11 +697,14 @@ def main():
             out["verification"]["all_ranks_ok"] = bool(all_ok)
         if loop_closure is not None:
             out["loop_closure"] = loop_closure
+        if single is not None:
+            out["single_frame_host_path"] = single
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, args.cpu_budget)
         print(json.dumps(out), flush=True)
 
-    ext.close()
+    for e_ in exts:
+        e_.close()
     mat.close()
     if dist is not None:
         dist.barrier()
