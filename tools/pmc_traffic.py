@@ -21,8 +21,11 @@ def main():
     frames = 1024 * 3      # prof_extract.py --pairs 512 --iters 3
     # calibration: the 1 GiB torch copy (elementwise copy kernel, 16 B per lane) must fetch 2^30 bytes
     cal = fe[fe.Kernel_Name.str.contains("elementwise|copy|Copy", regex=True) & (fe.Counter_Value > 100000)]
-    cal_kb = float(cal.Counter_Value.max()) if len(cal) else float("nan")
-    factor = (2 ** 30 / 1024.0) / cal_kb if cal_kb == cal_kb else 2.0
+    if not len(cal):
+        sys.exit("pmc_traffic.py: the 1 GiB calibration copy (prof_extract.py --calibrate) is not in the FETCH_SIZE pass: "
+                 "refusing to guess the gfx950 FETCH_SIZE correction factor")
+    cal_kb = float(cal.Counter_Value.max())
+    factor = (2 ** 30 / 1024.0) / cal_kb
     out = {"chunk": chunk, "fetch_calibration": {"copy_bytes": 2 ** 30, "FETCH_SIZE_kb_reported": cal_kb, "factor": round(factor, 3)},
            "kernels": {}}
     for k in sorted(set(fe.k.dropna())):
