@@ -632,19 +632,22 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     uint8_t (*s_raw)[kDescRows * kDescPitch] = s_patch;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
-    // regular pass: one trip (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks
-    // (ARENA is a template parameter: the regular pass compiles to straight-line code, exactly one trip)
-    const int n_blk = ARENA ? (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp : (int)blockIdx.x + 1;
-    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    // regular pass: one call (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks. The body
+    // is a lambda so that the regular instantiation stays straight-line code.
+    auto describe_block = [&](const int blk_in) {
+    const int blk = __builtin_amdgcn_readfirstlane(blk_in);     // block-uniform: keep the frame / level bookkeeping on the scalar unit
     int frame, l = 0, base = 0, nk;
     uint4 sv;
     if (!ARENA) {
         // XCD-aware block -> (frame, slot) map: workgroups are dealt round-robin over the 8 XCDs (speed only, never
         // correctness); give every XCD whole frames so a frame's patches are fetched into one L2.
         const int xcd = blk & 7, j = blk >> 3;
-        frame = (j / blocks_per_frame) * 8 + xcd;
-        if (frame >= n_frames) continue;
-        const int slot0 = (j % blocks_per_frame) * kDescKp + wv * 4;      // first of this wave's four slots (one level)
+        // (the division expands to vector code even for uniform operands: pin the result back to the scalar unit, or every
+        // frame-dependent address below is computed per lane)
+        frame = __builtin_amdgcn_readfirstlane((j / blocks_per_frame) * 8 + xcd);
+        if (frame >= n_frames) return;
+        const int jm = __builtin_amdgcn_readfirstlane(j % blocks_per_frame);
+        const int slot0 = __builtin_amdgcn_readfirstlane(jm * kDescKp + wv * 4);      // first of this wave's four slots (one level)
         const int* cnt = sel_cnt + frame * kLevels;
         int total = 0;
 #pragma unroll
@@ -659,22 +662,23 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
             counts[frame] = min(total, kp_cap);
             if (total > kp_cap) atomicMax(err + 2, total);
         }
-        if (slot0 >= P.sel_frame_entries) continue;
+        if (slot0 >= P.sel_frame_entries) return;
         l = __builtin_amdgcn_readfirstlane(l);     // the wave's four slots are in one level: keep the level geometry scalar
+        base = __builtin_amdgcn_readfirstlane(base);
         const int i0 = slot0 - P.lv[l].sel_off;
         nk = min(4, min(cnt[l], P.lv[l].sel_cap) - i0);                    // valid keypoints of this wave
-        if (nk <= 0) continue;
+        if (nk <= 0) return;
         // slots hold the level's keypoints in tile order; the record says which row of the output it is
         sv = sel[(int64_t)frame * P.sel_frame_entries + slot0 + min(grp, nk - 1)];
     } else {
         // arena pass: keypoints of tie-storm levels beyond the level's regular slots (k_select_ovf), in blocks of four
         // entries of one (frame, level); .w = frame | level << 24, rank 0xFFFFFFFF = padding (at the end of a block)
         const int e0 = blk * kDescKp + wv * 4;
-        if (e0 >= min(ovf[1], osel_cap)) continue;
+        if (e0 >= min(ovf[1], osel_cap)) return;
         const uint4 mine = osel[e0 + grp];
         const unsigned long long vm = __ballot(mine.z != 0xFFFFFFFFu && l16 == 0);
         nk = __popcll(vm);
-        if (nk <= 0) continue;
+        if (nk <= 0) return;
         const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine.w);
         frame = (int)(tag & 0xFFFFFFu);
         l = (int)(tag >> 24);
@@ -855,6 +859,12 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
             kps[orow] = k;
         }
     }
+    };
+    if constexpr (!ARENA) {
+        describe_block((int)blockIdx.x);
+    } else {
+        const int n_blk = (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp;
+        for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) describe_block(blk);
     }
     DSTAMP(6);
 #undef DSTAMP
