@@ -143,11 +143,22 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
     return ((float)a * (float)b - (float)c * (float)c - k * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
 }
 
+__device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
+                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                int* __restrict__ ovf, unsigned long long* __restrict__ keys, long long keys_cap,
+                                uint4* __restrict__ osel, int osel_cap, int frame, int l, int* s_hist, int* s_misc);
+
+// INLINE_OVF = false (batches): tie storms go to a work list and k_select_ovf. true (single-frame latency schedule: one
+// launch less): the overflowing workgroup runs the global-memory selection itself; ovf_items then carries the key arena.
+template <bool INLINE_OVF>
 __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint4* __restrict__ sel, int* __restrict__ sel_cnt,
                                                 int* __restrict__ err, unsigned long long* __restrict__ stamps,
-                                                int* __restrict__ ovf, int2* __restrict__ ovf_items) {
+                                                int* __restrict__ ovf, int2* __restrict__ ovf_items,
+                                                unsigned long long* __restrict__ ovf_keys, long long ovf_keys_cap,
+                                                uint4* __restrict__ osel, int osel_cap) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     SSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
@@ -258,6 +269,12 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     if (n1 > kSortCap) {
         // more candidates tie at the FAST cut than the LDS sort holds (a tie storm: checkerboards, synthetic patterns).
         // OpenCV's retainBest keeps them all, so this (frame, level) is redone by k_select_ovf in global memory.
+        if (INLINE_OVF) {
+            __shared__ __attribute__((aligned(8))) int s_ovm[8];
+            select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l,
+                            s_hist, s_ovm);
+            return;
+        }
         if (tid == 0) {
             sel_cnt[frame * kLevels + l] = 0;
             const int it = atomicAdd(&ovf[0], 1);
@@ -326,6 +343,12 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         n2 = q + s_misc[2];
     }
     if (n2 > g.sel_cap) {      // more ties at the Harris cut than the level's slots hold: same fallback
+        if (INLINE_OVF) {
+            __shared__ __attribute__((aligned(8))) int s_ovm[8];
+            select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l,
+                            s_hist, s_ovm);
+            return;
+        }
         if (tid == 0) {
             sel_cnt[frame * kLevels + l] = 0;
             const int it = atomicAdd(&ovf[0], 1);
@@ -402,18 +425,14 @@ __device__ __forceinline__ void ovf_st(unsigned long long* p, unsigned long long
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
-                                                    const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
-                                                    uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
-                                                    int* __restrict__ ovf, const int2* __restrict__ ovf_items,
-                                                    unsigned long long* __restrict__ keys, long long keys_cap,
-                                                    uint4* __restrict__ osel, int osel_cap) {
-    __shared__ int s_hist[256];
-    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena base (-1: none), [4] osel base
+// One (frame, level) through the global-memory selection (all 256 threads of the calling workgroup, uniformly).
+__device__ __attribute__((noinline)) void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
+                                const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                int* __restrict__ ovf, unsigned long long* __restrict__ keys, long long keys_cap,
+                                uint4* __restrict__ osel, int osel_cap, int frame, int l, int* s_hist, int* s_misc) {
     const int tid = threadIdx.x;
-    const int n_items = min(ovf[0], kOvfItems);
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int frame = ovf_items[it].x, l = ovf_items[it].y;
+    {
         const LevelGeom g = P.lv[l];
         const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
         const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const ui
             s_misc[5] = n1;
         }
         __syncthreads();
-        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; continue; }
+        if (s_misc[3] < 0) { if (tid == 0) sel_cnt[frame * kLevels + l] = 0; return; }
         const int thr = s_misc[0], n1 = s_misc[5];
         unsigned long long* K = keys + reinterpret_cast<long long*>(s_misc + 6)[0];
         long long np = 1;
@@ -518,6 +537,20 @@ __global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const ui
             for (int i = extra + tid; i < extra4; i += 256) osel[ob + i] = make_uint4(0u, 0u, 0xFFFFFFFFu, tag);   // padding
         if (tid == 0) sel_cnt[frame * kLevels + l] = n2;
     }
+}
+
+__global__ __launch_bounds__(256) void k_select_ovf(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                    const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
+                                                    uint4* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ err,
+                                                    int* __restrict__ ovf, const int2* __restrict__ ovf_items,
+                                                    unsigned long long* __restrict__ keys, long long keys_cap,
+                                                    uint4* __restrict__ osel, int osel_cap) {
+    __shared__ int s_hist[256];
+    __shared__ __attribute__((aligned(8))) int s_misc[8];   // [0] FAST cut, [1] keys written, [2] ties beyond q, [3] key arena ok, [4] osel base, [5] n1, [6..7] key base
+    const int n_items = min(ovf[0], kOvfItems);
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x)
+        select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, keys, keys_cap, osel, osel_cap, ovf_items[it].x,
+                        ovf_items[it].y, s_hist, s_misc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -615,7 +648,11 @@ __device__ __forceinline__ int row16_sum(int v) {
 //   IC moments : columns u = 2*l16-15, 2*l16-14 over the 31 rows of the disc, DPP row reduction
 //   rBRIEF     : test 16*it + l16 for it = 0..15; one 64-bit ballot per iteration carries 16 descriptor bits for each
 //                of the four keypoints; lane l16 keeps word l16 and stores its two bytes
-template <bool ARENA>
+// MODE 0: the frames' regular slots (batches). MODE 1: only the tie-storm arena (batches: a second, tiny launch). MODE 2:
+// both in one launch -- the regular blocks, then kDescArenaBlocks blocks that stride over the arena (single-frame latency
+// schedule: one launch less; in a batch the extra code costs the regular blocks registers).
+constexpr int kDescArenaBlocks = 32;
+template <int MODE>
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint4* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
@@ -634,7 +671,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     const int grp = lane >> 4, l16 = lane & 15;
     // regular pass: one call (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks. The body
     // is a lambda so that the regular instantiation stays straight-line code.
-    auto describe_block = [&](const int blk_in) {
+    const int n_regular = MODE == 2 ? (int)gridDim.x - kDescArenaBlocks : (int)gridDim.x;
+    auto describe_block = [&](const int blk_in, const bool ARENA) {
     const int blk = __builtin_amdgcn_readfirstlane(blk_in);     // block-uniform: keep the frame / level bookkeeping on the scalar unit
     int frame, l = 0, base = 0, nk;
     uint4 sv;
@@ -860,11 +898,18 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
         }
     }
     };
-    if constexpr (!ARENA) {
-        describe_block((int)blockIdx.x);
-    } else {
+    if constexpr (MODE == 0) {
+        describe_block((int)blockIdx.x, false);
+    } else if constexpr (MODE == 1) {
         const int n_blk = (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp;
-        for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) describe_block(blk);
+        for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) describe_block(blk, true);
+    } else {
+        if ((int)blockIdx.x < n_regular) {
+            describe_block((int)blockIdx.x, false);
+        } else {
+            const int n_blk = (min(ovf[1], osel_cap) + kDescKp - 1) / kDescKp;
+            for (int blk = (int)blockIdx.x - n_regular; blk < n_blk; blk += kDescArenaBlocks) describe_block(blk, true);
+        }
     }
     DSTAMP(6);
 #undef DSTAMP
@@ -941,7 +986,9 @@ int LaunchCtx::init(int dev) {
     const EnvConfig& E = env_config();
     // kernels that may need more than the default 64 KB of dynamic LDS: the attribute belongs to (function, device),
     // so every handle sets it for its own device
-    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(unsigned long long) * kSortCapMax)));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(sizeof(unsigned long long) * kSortCapMax)));
     if (int prc = pyramid_set_attributes(); prc != ARIA_OK) return prc;
     int rc = band_set_attributes();
@@ -1008,9 +1055,16 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     // diagnostic: ARIA_SEL_STAMPS=1 prints mean phase lengths per level
     unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;
     if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
-    ARIA_LAUNCH(prof, k_select, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
-                st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items);
+    if (latency)
+        ARIA_LAUNCH(prof, k_select<true>, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
+                    st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items, D.ovf_keys,
+                    D.ovf_keys_cap, D.osel, D.osel_cap);
+    else
+        ARIA_LAUNCH(prof, k_select<false>, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
+                    st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items, D.ovf_keys,
+                    D.ovf_keys_cap, D.osel, D.osel_cap);
     // tie-storm fallback: a fixed small grid that finds the work list empty on ordinary images
+    if (!latency)
     ARIA_LAUNCH(prof, k_select_ovf, dim3(64), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err,
                 D.ovf, D.ovf_items, D.ovf_keys, D.ovf_keys_cap, D.osel, D.osel_cap);
     if (sstp) {
@@ -1041,13 +1095,19 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         // diagnostic: ARIA_DESC_STAMPS=1 prints mean phase lengths
         unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
-        ARIA_LAUNCH(prof, k_describe<false>, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
-                    D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
-                    (const int*)nullptr, 0);
-        // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
-        ARIA_LAUNCH(prof, k_describe<true>, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
-                    D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
-                    (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
+        if (latency) {
+            ARIA_LAUNCH(prof, k_describe<2>, dim3((unsigned)(bpf * frames8 + kDescArenaBlocks)), dim3(64 * kDescWaves), 0, st, P, S,
+                        D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp,
+                        (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
+        } else {
+            ARIA_LAUNCH(prof, k_describe<0>, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
+                        D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
+                        (const int*)nullptr, 0);
+            // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
+            ARIA_LAUNCH(prof, k_describe<1>, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
+                        D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
+                        (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
+        }
         if (stp) {
             hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(nwaves * 8);
