@@ -654,33 +654,50 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
 // 7-launch resize chain -- and then ONE launch runs the FAST/blur strips of all eight levels side by side.
 void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
                                      Profiler* prof, LaunchCtx& ctx) {
-    (void)ctx;
+    // Default: pyramid kernel, then ONE launch over the strips of all levels, in order on st.
+    // ARIA_LATENCY_FORK=1 (experiment, measured slower: 188 vs 135 us per frame, a second branch in the graph costs more
+    // in cross-queue signalling than the overlap gains): level 0 needs nothing but the source frame, so its strips run
+    // on a side stream beside the pyramid kernel and levels 1..7 follow the pyramid.
+    static const bool fork = [] { const char* e = getenv("ARIA_LATENCY_FORK"); return e && e[0] == '1'; }();
+    auto band = [&](int l_lo, int l_hi, hipStream_t s) {
+        BandAll ba{};
+        size_t lds = 0;
+        int nthr = 64, total = 0;
+        for (int l = 0; l < kLevels; l++) {
+            ba.first[l] = total;
+            if (l < l_lo || l >= l_hi) continue;        // no strips: blockIdx never maps to this level
+            const LevelGeom& g = P.lv[l];
+            // one strip per workgroup at every level (nb = 1): same code path, uniform block size = the widest level's
+            const int wq = (g.w + 3) & ~3, lpr = wq >> 2;
+            const int qpct = std::min(50, P.band_qpct0 + P.band_qstep * l);
+            int qcap = (int)((int64_t)kBandR * wq * qpct / 100);
+            qcap = std::max(512, (qcap + 63) & ~63);
+            ba.qcap[l] = qcap;
+            total += (g.h + kBandR - 1) / kBandR;
+            lds = std::max(lds, (size_t)(kBandR + 8) * (wq + 8) + 4 * (size_t)qcap);
+            nthr = std::max(nthr, ((lpr + 63) / 64) * 64);
+        }
+        ba.first[kLevels] = total;
+        if (total == 0) return;
+        const dim3 grid(total, n_frames);
+        if (P.tie_mode == 1)
+            ARIA_LAUNCH(prof, (k_fast_blur_band<1, 1>), grid, dim3(nthr), lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
+                        0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
+        else
+            ARIA_LAUNCH(prof, (k_fast_blur_band<0, 1>), grid, dim3(nthr), lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
+                        0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
+    };
+    const bool do_fork = fork && ctx.ev_fork && ctx.side[0];
+    if (do_fork) {
+        hipEventRecord(ctx.ev_fork, st);
+        hipStreamWaitEvent(ctx.side[0], ctx.ev_fork, 0);
+        band(0, 1, ctx.side[0]);
+        hipEventRecord(ctx.ev_join[0], ctx.side[0]);
+    }
     if (!launch_pyramid_fused(P, S, D, n_frames, st, prof))
         for (int l = 1; l < kLevels; l++) launch_pyramid_level(P, S, D, n_frames, st, prof, l);
-    BandAll ba{};
-    size_t lds = 0;
-    int nthr = 64, total = 0;
-    for (int l = 0; l < kLevels; l++) {
-        const LevelGeom& g = P.lv[l];
-        // one strip per workgroup at every level (nb = 1): same code path, uniform block size = the widest level's
-        const int wq = (g.w + 3) & ~3, lpr = wq >> 2;
-        const int qpct = std::min(50, P.band_qpct0 + P.band_qstep * l);
-        int qcap = (int)((int64_t)kBandR * wq * qpct / 100);
-        qcap = std::max(512, (qcap + 63) & ~63);
-        ba.first[l] = total;
-        ba.qcap[l] = qcap;
-        total += (g.h + kBandR - 1) / kBandR;
-        lds = std::max(lds, (size_t)(kBandR + 8) * (wq + 8) + 4 * (size_t)qcap);
-        nthr = std::max(nthr, ((lpr + 63) / 64) * 64);
-    }
-    ba.first[kLevels] = total;
-    const dim3 grid(total, n_frames);
-    if (P.tie_mode == 1)
-        ARIA_LAUNCH(prof, (k_fast_blur_band<1, 1>), grid, dim3(nthr), lds, st, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
-                    0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
-    else
-        ARIA_LAUNCH(prof, (k_fast_blur_band<0, 1>), grid, dim3(nthr), lds, st, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
-                    0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
+    band(do_fork ? 1 : 0, kLevels, st);
+    if (do_fork) hipStreamWaitEvent(st, ctx.ev_join[0], 0);
 }
 
 }  // namespace aria

@@ -102,14 +102,16 @@ template <int MODE, bool WIDE, int NC, int TT>   // NC column tiles (of 32 queri
 __device__ __forceinline__ void knn2_body(
     const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, const uint8_t* __restrict__ t,
     const int* __restrict__ nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* __restrict__ keys, int maxq,
-    double ratio, int* __restrict__ good) {
+    double ratio, int* __restrict__ good, int tsplit) {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][TT * kRowB];
     __shared__ __attribute__((aligned(16))) int s_base[2][TT];    // [buf][train of the tile]: accumulator preload
     __shared__ int s_cnt;
     constexpr int QB = 128 * NC;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, hh = lane >> 5;
-    const int pair = blockIdx.y;
+    // tsplit > 0 (one pair, latency schedule): blockIdx.y is a slice of tsplit train tiles of pair 0 and writes its own
+    // row of keys (global train indices); the consumer merges the rows (k_ratio_compact)
+    const int pair = tsplit ? 0 : blockIdx.y;
     const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
     const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
     if ((int)blockIdx.x * QB >= nq) return;
@@ -163,11 +165,12 @@ __device__ __forceinline__ void knn2_body(
 #pragma unroll
         for (int p = 0; p < 2; p++) { m1[c][p] = __int_as_float(0x7F7FFFFF); m2[c][p] = __int_as_float(0x7F7FFFFF); }
 
-    const int ntiles = (nt + TT - 1) / TT;
-    if (ntiles > 0) { load_tile(0); store_tile(0, 0); }
+    const int it0 = tsplit ? (int)blockIdx.y * tsplit : 0;
+    const int ntiles = tsplit ? min((nt + TT - 1) / TT, it0 + tsplit) : (nt + TT - 1) / TT;
+    if (ntiles > it0) { load_tile(it0); store_tile(it0, 0); }
     __syncthreads();
-    for (int it = 0; it < ntiles; it++) {
-        const int buf = it & 1;
+    for (int it = it0; it < ntiles; it++) {
+        const int buf = (it - it0) & 1;
         load_tile(it + 1);
 #pragma unroll
         for (int rt = 0; rt < NR; rt++) {
@@ -220,7 +223,7 @@ __device__ __forceinline__ void knn2_body(
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const int qi = q0 + 32 * c + col;
-                if (qi < nq) keys[(int64_t)pair * maxq + qi] = make_uint2(k0[c], k1[c]);
+                if (qi < nq) keys[(int64_t)(tsplit ? blockIdx.y : pair) * maxq + qi] = make_uint2(k0[c], k1[c]);
             }
         }
     } else {
@@ -247,17 +250,17 @@ template <int MODE, bool WIDE, int NC, int TT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_knn2_mfma(
     const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed, const uint8_t* __restrict__ t,
     const int* __restrict__ nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* __restrict__ keys, int maxq,
-    double ratio, int* __restrict__ good) {
-    knn2_body<MODE, WIDE, NC, TT>(q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride, keys, maxq, ratio, good);
+    double ratio, int* __restrict__ good, int tsplit) {
+    knn2_body<MODE, WIDE, NC, TT>(q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride, keys, maxq, ratio, good, tsplit);
 }
 
 template <int MODE, bool WIDE, int NC, int TT>
 void launch_one(int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed, const uint8_t* t,
                 const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* keys, int maxq, double ratio,
-                int* good) {
-    const dim3 grid((unsigned)((nq_max + 128 * NC - 1) / (128 * NC)), (unsigned)n_pairs);
+                int* good, int tsplit = 0, int nsplit = 1) {
+    const dim3 grid((unsigned)((nq_max + 128 * NC - 1) / (128 * NC)), (unsigned)(tsplit ? nsplit : n_pairs));
     hipLaunchKernelGGL((k_knn2_mfma<MODE, WIDE, NC, TT>), grid, dim3(256), 0, st, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed,
-                       q_stride, t_stride, keys, maxq, ratio, good);
+                       q_stride, t_stride, keys, maxq, ratio, good, tsplit);
 }
 
 }  // namespace
@@ -283,6 +286,23 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
         else launch_one<1, false, 2, 64>(ARIA_KNN_ARGS);
     }
 #undef ARIA_KNN_ARGS
+}
+
+int knn2_split_count(int nq, int nt) {
+    const int qblocks = (nq + 255) / 256, ntiles = (nt + 63) / 64;
+    int want = std::max(1, std::min(kKnnSplitMax, 192 / std::max(qblocks, 1)));
+    const int per = std::max(1, (ntiles + want - 1) / want);
+    return std::max(1, (ntiles + per - 1) / per);
+}
+
+void launch_knn2_mfma_split(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint2* keys, int maxq,
+                            int nsplit) {
+    if (nq <= 0 || nsplit <= 0) return;
+    const int ntiles = (nt + 63) / 64, per = std::max(1, (ntiles + nsplit - 1) / nsplit);
+    if (nt > kNarrowMax)
+        launch_one<0, true, 2, 64>(nq, 1, st, q, nullptr, nq, t, nullptr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
+    else
+        launch_one<0, false, 2, 64>(nq, 1, st, q, nullptr, nq, t, nullptr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
 }
 
 }  // namespace aria

@@ -135,13 +135,15 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
 // compaction uses wave ballots + popcount prefixes.
 // qflags / tflags (optional): per-keypoint "lies in a dynamic object" flags of the query / train frame of every pair
 // (k_flag_keypoints); a ratio-test survivor with a flagged endpoint is dropped and counted (src/main.cpp:164-175).
-__global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__ keys, const int* __restrict__ nq_arr,
+template <int NT>      // threads: 256 per pair for batches, 1024 for the single pair of the latency schedule
+__global__ __launch_bounds__(NT) void k_ratio_compact(const uint2* __restrict__ keys, const int* __restrict__ nq_arr,
                                                        int nq_fixed, int maxq, float ratio,
                                                        aria_match* __restrict__ out, int* __restrict__ nout, int cap,
                                                        int* __restrict__ err, const uint8_t* __restrict__ qflags = nullptr,
                                                        const uint8_t* __restrict__ tflags = nullptr, int64_t flag_stride = 0,
-                                                       int* __restrict__ nfiltered = nullptr) {
-    __shared__ int s_w[4];
+                                                       int* __restrict__ nfiltered = nullptr, int nsplit = 1) {
+    constexpr int NW = NT / 64;
+    __shared__ int s_w[NW];
     __shared__ int s_f;
     if (threadIdx.x == 0) s_f = 0;
     __syncthreads();
@@ -151,12 +153,25 @@ __global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__
     const uint2* kk = keys + (int64_t)pair * maxq;
     aria_match* o = out + (int64_t)pair * cap;
     int base = 0;
-    for (int q0 = 0; q0 < nq; q0 += 256) {
+    for (int q0 = 0; q0 < nq; q0 += NT) {
         const int qi = q0 + tid;
         bool ok = false;
         uint2 k = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         if (qi < nq) {
             k = kk[qi];
+            // train slices of the latency schedule (one pair): two smallest of all; loads four at a time
+            for (int s0 = 1; s0 < nsplit; s0 += 4) {
+                uint2 o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = kk[(int64_t)min(s0 + j, nsplit - 1) * maxq + qi];   // clamped loads past the last slice are not merged
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (s0 + j >= nsplit) break;
+                    const uint32_t lo = min(k.x, o[j].x);
+                    k.y = min(max(k.x, o[j].x), min(k.y, o[j].y));
+                    k.x = lo;
+                }
+            }
             if (ratio == 0.0f) ok = k.x != 0xFFFFFFFFu;   // IMatcher.hpp:18 "0.0 = disabled"
             else ok = k.y != 0xFFFFFFFFu && (float)(k.x >> 16) < ratio * (float)(k.y >> 16);
             if (ok && qflags && (qflags[(int64_t)pair * flag_stride + qi] | tflags[(int64_t)pair * flag_stride + (k.x & 0xFFFFu)])) {
@@ -167,9 +182,12 @@ __global__ __launch_bounds__(256) void k_ratio_compact(const uint2* __restrict__
         const unsigned long long m = __ballot(ok);
         if (lane == 0) s_w[wv] = __popcll(m);
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wv; w++) off += s_w[w];
-        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (w < wv) off += s_w[w];
+            tot += s_w[w];
+        }
         off += __popcll(m & ((1ull << lane) - 1ull));
         if (ok) {
             if (off < cap) {
@@ -251,6 +269,29 @@ struct aria_matcher_s {
     aria_match* h_m = nullptr;      // pinned
     int* h_n = nullptr;             // pinned [0] n, [1] err
     int* h_idx = nullptr;           // pinned
+    // aria_matcher_match keeps the last two query sets on the device (ping-pong) and their bytes in pinned staging: a
+    // front end matches frame i against frame i-1, i.e. the train set of a call is the query set of the call before,
+    // which then is not uploaded again. Results come back in one copy: [4-int header: count][matches].
+    uint8_t* d_pp[2] = {nullptr, nullptr};
+    uint8_t* h_pp[2] = {nullptr, nullptr};
+    int pp_n[2] = {-1, -1};
+    int pp_cur = 0;
+    uint8_t* d_res = nullptr;       // [16 B header][max_query matches]
+    uint8_t* h_res = nullptr;       // pinned
+    // the four operations of aria_matcher_match as a hipGraph per ping-pong slot, keyed on the sizes; captured when a key
+    // shows up the second time in a row for its slot (a stream of frames with the same keypoint count), eager otherwise
+    struct MatchGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int nq = -1, nt = -1, hit = -1; float ratio = -1.f;              // key of exec
+        int seen_nq = -1, seen_nt = -1, seen_hit = -1; float seen_ratio = -1.f;
+        void drop() {
+            if (exec) hipGraphExecDestroy(exec);
+            if (graph) hipGraphDestroy(graph);
+            exec = nullptr; graph = nullptr; nq = nt = hit = -1;
+        }
+    } mg[2];
+    bool graph_failed = false;
     // one-query-against-many path (IMatcher::matchMultiple / loop candidates): grow-only staging
     uint8_t* d_multi = nullptr;     // [n_cand][multi_rows * 32]
     int* d_mcnt = nullptr;          // [n_cand] rows per candidate, then [n_cand] results (matches or good counts)
@@ -322,6 +363,11 @@ int ensure_keys(aria_matcher_s* m, size_t entries) {
 void matcher_free(aria_matcher_s* m) {
     hipFree(m->d_keys); hipFree(m->d_err); hipFree(m->d_q); hipFree(m->d_t); hipFree(m->d_m); hipFree(m->d_n);
     hipFree(m->d_idx); hipFree(m->d_multi); hipFree(m->d_mcnt); hipFree(m->d_mm);
+    m->mg[0].drop(); m->mg[1].drop();
+    hipFree(m->d_pp[0]); hipFree(m->d_pp[1]); hipFree(m->d_res);
+    if (m->h_pp[0]) hipHostFree(m->h_pp[0]);
+    if (m->h_pp[1]) hipHostFree(m->h_pp[1]);
+    if (m->h_res) hipHostFree(m->h_res);
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->h_m) hipHostFree(m->h_m);
     if (m->h_n) hipHostFree(m->h_n);
@@ -341,7 +387,13 @@ int matcher_alloc(aria_matcher_s* m) {
     ARIA_HIP(hipHostMalloc(&m->h_m, nq * sizeof(aria_match)));
     ARIA_HIP(hipHostMalloc(&m->h_n, 2 * sizeof(int)));
     ARIA_HIP(hipHostMalloc(&m->h_idx, nq * 4 * sizeof(int)));
-    return ensure_keys(m, nq);
+    for (int k = 0; k < 2; k++) {
+        ARIA_HIP(hipMalloc(&m->d_pp[k], nq * 32));
+        ARIA_HIP(hipHostMalloc(&m->h_pp[k], nq * 32));
+    }
+    ARIA_HIP(hipMalloc(&m->d_res, 16 + nq * sizeof(aria_match)));
+    ARIA_HIP(hipHostMalloc(&m->h_res, 16 + nq * sizeof(aria_match)));
+    return ensure_keys(m, nq * (size_t)kKnnSplitMax);
 }
 
 int upload_pair(aria_matcher_s* m, const uint8_t* q, int nq, const uint8_t* t, int nt) {
@@ -438,6 +490,32 @@ int aria_matcher_sync(aria_matcher_t m) {
     return errbits_to_status(bits);
 }
 
+// The device work of one aria_matcher_match call on m->stream: upload of the query set into ping-pong slot cur (and of
+// the train set unless it is resident as the other slot), kNN-2 in train slices, ratio test + compaction with the
+// slice merge, one copy back ([count][matches]).
+static int enqueue_match_ops(aria_matcher_s* m, int cur, bool hit, int nq, int nt, float ratio) {
+    const uint8_t* d_train = m->d_pp[cur ^ 1];
+    if (!hit) {
+        ARIA_HIP(hipMemcpyAsync(m->d_t, m->h_stage, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+        d_train = m->d_t;
+    }
+    ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], m->h_pp[cur], (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    int nsplit = 1;
+    if (m->knn_valu) {
+        launch_knn2(m, 0, nq, 1, m->d_pp[cur], nullptr, nq, d_train, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
+                    m->max_query, 0.0, nullptr, nt);
+    } else {
+        nsplit = knn2_split_count(nq, nt);
+        launch_knn2_mfma_split(m->stream, m->d_pp[cur], nq, d_train, nt, m->d_keys, m->max_query, nsplit);
+    }
+    hipLaunchKernelGGL(k_ratio_compact<1024>, dim3(1), dim3(1024), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
+                       reinterpret_cast<aria_match*>(m->d_res + 16), reinterpret_cast<int*>(m->d_res), m->max_query, m->d_err,
+                       nullptr, nullptr, (int64_t)0, nullptr, nsplit);
+    ARIA_HIP(hipGetLastError());
+    ARIA_HIP(hipMemcpyAsync(m->h_res, m->d_res, 16 + sizeof(aria_match) * (size_t)nq, hipMemcpyDeviceToHost, m->stream));
+    return ARIA_OK;
+}
+
 int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
                        aria_match* matches, int cap, int* n_out) {
     if (!m || !n_out || nq < 0 || nt < 0 || cap < 0) return ARIA_E_INVALID;
@@ -446,22 +524,50 @@ int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t
     if (!q || !t) return ARIA_E_INVALID;
     if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
     ARIA_HIP(hipSetDevice(m->device));
-    int rc = upload_pair(m, q, nq, t, nt);
-    if (rc != ARIA_OK) return rc;
-    launch_knn2(m, 0, nq, 1, m->d_q, nullptr, nq, m->d_t, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
-                m->max_query, 0.0, nullptr, nt);
-    hipLaunchKernelGGL(k_ratio_compact, dim3(1), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
-                       m->d_m, m->d_n, m->max_query, m->d_err);
-    ARIA_HIP(hipGetLastError());
-    ARIA_HIP(hipMemcpyAsync(m->h_n, m->d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ARIA_HIP(hipMemcpyAsync(m->h_m, m->d_m, sizeof(aria_match) * (size_t)nq, hipMemcpyDeviceToHost, m->stream));
+    // train set = the query set of the previous call (frame i-1)? then it is on the device already
+    const int prev = m->pp_cur, cur = prev ^ 1;
+    const bool hit = m->pp_n[prev] == nt && nt <= m->max_query && std::memcmp(m->h_pp[prev], t, (size_t)nt * 32) == 0;
+    if (!hit) std::memcpy(m->h_stage, t, (size_t)nt * 32);
+    std::memcpy(m->h_pp[cur], q, (size_t)nq * 32);
+    m->pp_n[cur] = nq;
+    m->pp_cur = cur;
+    static const bool want_graph = [] { const char* e = getenv("ARIA_MATCH_GRAPH"); return !(e && e[0] == '0'); }();
+    aria_matcher_s::MatchGraph& G = m->mg[cur];
+    const int hit_i = hit ? 1 : 0;
+    if (want_graph && !m->graph_failed && G.exec && G.nq == nq && G.nt == nt && G.hit == hit_i && G.ratio == ratio) {
+        ARIA_HIP(hipGraphLaunch(G.exec, m->stream));
+    } else if (want_graph && !m->graph_failed && G.seen_nq == nq && G.seen_nt == nt && G.seen_hit == hit_i && G.seen_ratio == ratio) {
+        G.drop();
+        ARIA_HIP(hipStreamSynchronize(m->stream));
+        hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
+        int rc = ARIA_OK;
+        if (e == hipSuccess) {
+            rc = enqueue_match_ops(m, cur, hit, nq, nt, ratio);
+            e = hipStreamEndCapture(m->stream, &G.graph);
+        }
+        if (e == hipSuccess && rc == ARIA_OK) e = hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0);
+        if (e != hipSuccess || rc != ARIA_OK || !G.exec) {
+            G.drop();
+            (void)hipGetLastError();
+            m->graph_failed = true;
+            rc = enqueue_match_ops(m, cur, hit, nq, nt, ratio);
+            if (rc != ARIA_OK) return rc;
+        } else {
+            G.nq = nq; G.nt = nt; G.hit = hit_i; G.ratio = ratio;
+            ARIA_HIP(hipGraphLaunch(G.exec, m->stream));
+        }
+    } else {
+        int rc = enqueue_match_ops(m, cur, hit, nq, nt, ratio);
+        if (rc != ARIA_OK) return rc;
+    }
+    G.seen_nq = nq; G.seen_nt = nt; G.seen_hit = hit_i; G.seen_ratio = ratio;
     ARIA_HIP(hipStreamSynchronize(m->stream));
-    const int n = m->h_n[0];
+    const int n = reinterpret_cast<const int*>(m->h_res)[0];
     *n_out = n;
     if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
     if (n > 0) {
         if (!matches) return ARIA_E_INVALID;
-        std::memcpy(matches, m->h_m, sizeof(aria_match) * (size_t)n);
+        std::memcpy(matches, m->h_res + 16, sizeof(aria_match) * (size_t)n);
     }
     return ARIA_OK;
 }
@@ -516,7 +622,7 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
         hipStreamSynchronize(m->stream);
         hipEventRecord(ev.e[2], m->stream);
     }
-    hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
+    hipLaunchKernelGGL(k_ratio_compact<256>, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
                        d_matches, d_nmatches, match_cap, m->d_err);
     if (p1) { hipEventRecord(ev.e[3], m->stream); hipStreamSynchronize(m->stream); }
     if (m->prof_enabled) m->prof_pending.push_back(ev);
@@ -550,7 +656,7 @@ int aria_matcher_match_batch_filtered_device(aria_matcher_t m, const uint8_t* d_
     if (rc != ARIA_OK) return rc;
     launch_knn2(m, 0, (int)maxq, n_pairs, d_query, d_nq, 0, d_train, d_nt, 0, desc_stride, desc_stride, m->d_keys, (int)maxq,
                 0.0, nullptr, (int)maxq);
-    hipLaunchKernelGGL(k_ratio_compact, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
+    hipLaunchKernelGGL(k_ratio_compact<256>, dim3(n_pairs), dim3(256), 0, m->stream, m->d_keys, d_nq, 0, (int)maxq, ratio,
                        d_matches, d_nmatches, match_cap, m->d_err, d_qflags, d_tflags, flag_stride, d_nfiltered);
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
@@ -629,7 +735,7 @@ int aria_matcher_match_multi(aria_matcher_t m, const uint8_t* q, int nq, const u
     // one launch over all candidates: the query block is shared (stride 0), candidate c is train block c
     launch_knn2(m, 0, nq, n_cand, m->d_q, nullptr, nq, m->d_multi, m->d_mcnt, 0, (int64_t)0, (int64_t)rows * 32, m->d_keys,
                 m->max_query, 0.0, nullptr, rows);
-    hipLaunchKernelGGL(k_ratio_compact, dim3(n_cand), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
+    hipLaunchKernelGGL(k_ratio_compact<256>, dim3(n_cand), dim3(256), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
                        m->d_mm, m->d_mcnt + n_cand, m->max_query, m->d_err);
     ARIA_HIP(hipGetLastError());
     std::vector<int> cnt((size_t)n_cand);

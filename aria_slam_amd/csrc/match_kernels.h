@@ -14,4 +14,13 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
                       const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
                       uint2* keys, int maxq, double ratio, int* good, int max_train);
 
+// Latency schedule for ONE pair (frame-at-a-time host path): the train set is cut into nsplit slices of whole 64-train
+// tiles, every (query block, slice) is a workgroup, slice s writes keys[s * maxq + query] with GLOBAL train indices;
+// the consumer takes the two smallest of the 2 nsplit keys of a query (k_ratio_compact's nsplit argument). A single
+// 2000 x 2000 pair is 8 workgroups on 256 CUs otherwise. knn2_split_count picks nsplit (<= kKnnSplitMax).
+constexpr int kKnnSplitMax = 16;
+int knn2_split_count(int nq, int nt);
+void launch_knn2_mfma_split(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint2* keys, int maxq,
+                            int nsplit);
+
 }  // namespace aria

@@ -4,6 +4,7 @@
 #include "orb_plan.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 
 #include "aria_orb_hip.h"
@@ -197,6 +198,10 @@ int build_pyramid_bands(Plan* P, const uint32_t* tab, int* out, int out_capacity
     // Note the halo: a band's deepest level needs one extra source row per level above it, amplified by 1.2 per
     // level, so small bands recompute a lot; measured slower than per-level launches at 640x480.
     const int budgets[3] = {53 * 1024, 80 * 1024, 150 * 1024};
+    if (const char* e = getenv("ARIA_PYR_BH")) {
+        const int n = pyramid_bands_for(P, tab, std::max(8, atoi(e) & ~7), out, out_capacity);
+        if (n > 0 && P->pyr_lds_bytes <= budgets[2]) return n;
+    }
     for (int bi = 0; bi < 3; bi++)
         for (int bh = 64; bh >= 8; bh -= 8) {
             const int n = pyramid_bands_for(P, tab, bh, out, out_capacity);

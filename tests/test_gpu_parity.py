@@ -109,6 +109,31 @@ def test_knn2_random_sets_with_ties(aria, oracle, nq, nt):
         m.close()
 
 
+def test_match_train_resident_from_previous_call(aria, oracle):
+    """aria_matcher_match keeps the previous call's query set on the device and skips the train upload when the train
+    bytes equal it (frame i against frame i-1). Hits, misses (other set, same size with one byte changed, other size)
+    and the slice merge of the latency schedule must all give the oracle's matches."""
+    rng = np.random.default_rng(77)
+    d = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in (700, 700, 1999, 2000, 2000)]
+    for x in d:
+        x[:, 6:] &= 0x33
+    near = d[3].copy()
+    near[-1, -1] ^= 1
+    m = aria.HipMatcher()
+    try:
+        calls = [(d[1], d[0]), (d[2], d[1]), (d[3], d[2]), (d[4], near), (d[0], d[4]), (d[1], d[1]), (d[1], d[1]), (d[2], d[0])]
+        # a steady stream of equal-sized frames, each matched against the one before: from the second sighting of a
+        # size on, a ping-pong slot replays its captured graph (different data every time)
+        chain = [d[3], d[4], near, d[3], d[4], near, d[3], d[4], near]
+        calls += [(chain[i], chain[i - 1]) for i in range(1, len(chain))]
+        calls += [(d[0], d[1]), (d[4], d[3]), (near, d[4])]            # size change in between, then back
+        for q, t in calls:
+            got = m.match({"descriptors": q}, {"descriptors": t}, None, 0.75)
+            assert got.tobytes() == oracle.match_ratio(q, t, 0.75).tobytes()
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("w,h,nf", [(2047, 2047, 3000), (1919, 1083, 1500), (96, 2047, 200)])
 def test_extract_bit_exact_large_and_limit_sizes(aria, oracle, w, h, nf):
     """The image-size limit of the candidate packing (2047 x 2047: widest staged rows, 32 x 32 selection tiles of 64 px),

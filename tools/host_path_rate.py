@@ -39,17 +39,21 @@ def main():
             ext(i, 0)
     t1 = time.perf_counter()
     ext(0, 1)
+    tm = 0.0
     for rep in range(reps // 2):
         for i in range(len(seq)):
             s = i & 1
             ext(i, s)
+            ta = time.perf_counter()
             rc = L.aria_matcher_match(m._h, ds[s].ctypes.data, n[s].value, ds[1 - s].ctypes.data, n[1 - s].value,
                                       C.c_float(0.75), mt.ctypes.data, cap, C.byref(nm))
+            tm += time.perf_counter() - ta
             assert rc == 0
     t2 = time.perf_counter()
     N1, N2 = reps * len(seq), (reps // 2) * len(seq)
     print("aria_orb_extract (host buffers)           : %.1f us/frame = %.0f frames/s" % (1e6 * (t1 - t0) / N1, N1 / (t1 - t0)))
-    print("aria_orb_extract + aria_matcher_match     : %.1f us/frame = %.0f frames/s" % (1e6 * (t2 - t1) / N2, N2 / (t2 - t1)))
+    print("aria_orb_extract + aria_matcher_match     : %.1f us/frame = %.0f frames/s (match calls alone %.1f us, %d..%d keypoints)"
+          % (1e6 * (t2 - t1) / N2, N2 / (t2 - t1), 1e6 * tm / N2, min(n[0].value, n[1].value), max(n[0].value, n[1].value)))
     # GPU-side stage times of one frame in flight (drained HIP-event brackets: adds host time, so not a rate)
     e.set_profiling(True)
     m.set_profiling(True)
