@@ -76,6 +76,7 @@ struct EnvConfig {
     int level_streams;     // ARIA_LEVEL_STREAMS=1: one side stream per level
     int stamp_level;       // ARIA_STAMPS=<level>: phase stamps of the band kernel, -1 = off
     int sel_stamps;        // ARIA_SEL_STAMPS=1
+    int select_bitonic;    // ARIA_SELECT_SORT=bitonic: k_select always takes its LDS bitonic sort (default: histogram bins + in-bin ranks)
     int desc_stamps;       // ARIA_DESC_STAMPS=1
     int fast_blur_impl;    // 2 = band kernel, all VALU (fast_blur_band.hip, default), 1 = band kernel with the blur on the
                            // matrix cores (band_mfma.hip, ARIA_FAST_BLUR_IMPL=mfma: same bits, 23 % fewer VALU instructions,

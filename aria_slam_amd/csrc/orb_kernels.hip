@@ -158,8 +158,13 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
                                                 int* __restrict__ err, unsigned long long* __restrict__ stamps,
                                                 int* __restrict__ ovf, int2* __restrict__ ovf_items,
                                                 unsigned long long* __restrict__ ovf_keys, long long ovf_keys_cap,
-                                                uint4* __restrict__ osel, int osel_cap) {
-#define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+                                                uint4* __restrict__ osel, int osel_cap, int force_bitonic) {
+    // Workgroups go round-robin to the 8 XCDs by linear id, and blockIdx.x has 8 values: with level = blockIdx.x one XCD
+    // would get every level-0 workgroup (5x the work of a level-7 one) and set the pace. Rotating by the frame index gives
+    // every XCD every level.
+    static_assert(kLevels == 8, "level rotation below assumes 8 levels");
+    const int l = (int)((blockIdx.x + blockIdx.y) & 7u), frame = blockIdx.y;
+#define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[((size_t)blockIdx.y * kLevels + l) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     SSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
     __shared__ int s_hist[256];
@@ -168,7 +173,6 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     __shared__ int s_bin[1024];   // keypoints per tile of the level
 
     const int tid = threadIdx.x;
-    const int l = blockIdx.x, frame = blockIdx.y;
     const LevelGeom g = P.lv[l];
     const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
     const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
@@ -283,52 +287,142 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         }
         return;
     }
-    int np = 1;
-    while (np < n1) np <<= 1;
-    for (int i = n1 + tid; i < np; i += 256) s_keys[i] = ~0ull;
+    // ---- order the keys: ascending on (~harris_order, y, x) == Harris descending, then y, then x ----
+    // Only the best q (+ ties) by Harris are kept, but retainBest(2q) on the integer FAST score hands over 2q plus a
+    // whole score bin of ties (often > 1024 keys at level 0), and a bitonic sort in LDS is a chain of ~50 dependent
+    // round trips + barriers whatever the size (27k cycles at level 0, 16k at level 7: half of this kernel). Instead:
+    //  1. 1024-bin histogram of the keys' Harris order bits (sign + exponent + 2 mantissa bits) and its prefix sum;
+    //  2. the bin that holds the q-th key closes the kept set -- a superset of "first q + ties with the q-th";
+    //  3. the kept keys are scattered to their bins (upper half of the key array), which orders them coarsely;
+    //  4. every key finds its exact place by counting the smaller keys of its own bin (a few dozen at most).
+    // Bins too full for that (> 512 keys of near-equal response) or a kept set beyond half the array: bitonic sort.
+    __shared__ int s_srt[2];   // [0] bin of the cut, [1] largest kept bin
+    auto hbin = [](unsigned long long kk) { return (int)min((uint32_t)(kk >> 53), 1023u); };
+    const bool cut = n1 > q + 64;
+    for (int i = tid; i < 1024; i += 256) s_bin[i] = 0;
+    if (tid == 0) { s_srt[0] = 1023; s_srt[1] = 0; }
     __syncthreads();
-    // bitonic sort, ascending on (~harris_order, y, x) == Harris descending, then y, then x
-    // Bitonic sort. Steps are taken two at a time: a thread loads the four keys (i, i+h, i+2h, i+3h) of a radix-4
-    // butterfly, does the compare-exchanges of step j = 2h and of step h in registers and stores them back -- one LDS
-    // round trip per two steps. (When a merge phase k has an odd number of steps its first one, j = k/2, goes alone, two
-    // pairs per thread, between workgroup barriers.) In butterfly steps a wave owns one aligned block of 256 keys; while
-    // consecutive butterflies stay inside it (span 2j <= 256) no workgroup barrier is needed -- the wave's LDS
-    // accesses are served in order.
-    auto steps_of = [](int kk) { int n = 0; for (int jj = kk >> 1; jj > 0; jj >>= 1) n++; return n; };
-    for (int k = 2; k <= np; k <<= 1) {
-        int j = k >> 1;
-        if (steps_of(k) & 1) {
-            __syncthreads();
-            for (int t0 = tid; t0 < (np >> 1); t0 += 512) {
-                const int ta = t0, tb = t0 + 256;
-                const bool hb = tb < (np >> 1);
-                const int a0 = ((ta & ~(j - 1)) << 1) | (ta & (j - 1)), a1 = a0 | j;
-                const int b0 = hb ? (((tb & ~(j - 1)) << 1) | (tb & (j - 1))) : a0, b1 = hb ? (b0 | j) : a1;
-                const unsigned long long xa = s_keys[a0], ya = s_keys[a1], xb = s_keys[b0], yb = s_keys[b1];
-                if ((xa > ya) == ((a0 & k) == 0)) { s_keys[a0] = ya; s_keys[a1] = xa; }
-                if (hb && (xb > yb) == ((b0 & k) == 0)) { s_keys[b0] = yb; s_keys[b1] = xb; }
-            }
-            __syncthreads();
-            j >>= 1;
+    for (int i = tid; i < n1; i += 256) atomicAdd(&s_bin[hbin(s_keys[i])], 1);
+    __syncthreads();
+    {   // thread t owns bins 4t .. 4t+3: exclusive prefix sum (= first slot of every bin), bin where the count crosses q
+        const int lane = tid & 63, wv = tid >> 6;
+        int b[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = s_bin[4 * tid + k]; tot += b[k]; }
+        int c = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(c, d);
+            if (lane >= d) c += o;
         }
-        for (; j > 1; j >>= 2) {
-            const int h = j >> 1;
-            for (int t = tid; t < (np >> 2); t += 256) {
-                const int i = ((t & ~(h - 1)) << 2) | (t & (h - 1));
-                unsigned long long e0 = s_keys[i], e1 = s_keys[i + h], e2 = s_keys[i + j], e3 = s_keys[i + j + h];
-                const bool up = (i & k) == 0;
-                unsigned long long tmp;
-                if ((e0 > e2) == up) { tmp = e0; e0 = e2; e2 = tmp; }       // step j
-                if ((e1 > e3) == up) { tmp = e1; e1 = e3; e3 = tmp; }
-                if ((e0 > e1) == up) { tmp = e0; e0 = e1; e1 = tmp; }       // step h
-                if ((e2 > e3) == up) { tmp = e2; e2 = e3; e3 = tmp; }
-                s_keys[i] = e0; s_keys[i + h] = e1; s_keys[i + j] = e2; s_keys[i + j + h] = e3;
+        if (lane == 63) s_wsum[wv] = c;
+        if (tid == 0) s_misc[1] = 0;          // (every wave has read n1 from it: two barriers ago)
+        __syncthreads();
+        int run = c - tot;
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+            if (w < wv) run += s_wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            s_bin[4 * tid + k] = run;
+            if (cut && run < q && run + b[k] >= q) s_srt[0] = 4 * tid + k;
+            run += b[k];
+        }
+        __syncthreads();
+        const int bc = s_srt[0];
+        int mx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (4 * tid + k <= bc) mx = max(mx, b[k]);
+        if (mx > 0) atomicMax(&s_srt[1], mx);
+    }
+    const int bcut = s_srt[0];
+    if (cut) {
+        // in-place compaction of the kept keys to the front, 256 keys per round: a round's keys are in registers before
+        // anyone writes (barrier), and writes only reach slots that this or an earlier round has consumed
+        for (int i0 = 0; i0 < n1; i0 += 256) {
+            const int i = i0 + tid;
+            const unsigned long long kk = i < n1 ? s_keys[i] : ~0ull;
+            const bool keep = i < n1 && hbin(kk) <= bcut;
+            __syncthreads();
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(m));
+                base = __shfl(base, leader);
+                if (keep) s_keys[base + __popcll(m & ((1ull << lane) - 1ull))] = kk;
             }
-            // what follows: a butterfly with top step j/4 of this phase, or the next phase (a butterfly with top step k
-            // if it has an even number of steps; a single step syncs for itself)
-            const int next_span = (j >> 2) > 1 ? 2 * (j >> 2) : ((k < np && !(steps_of(2 * k) & 1)) ? 2 * k : 0);
-            if (2 * j > 256 || next_span > 256 || np > 1024) __syncthreads();   // np > 1024: a thread makes several trips
-            else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+        }
+        __syncthreads();
+        n1 = s_misc[1];
+    } else {
+        __syncthreads();
+    }
+    const int upper = kSortCap >> 1;
+    if (n1 <= upper && s_srt[1] <= 512 && !force_bitonic) {
+        unsigned long long* s_up = s_keys + upper;
+        for (int i = tid; i < n1; i += 256) {
+            const unsigned long long kk = s_keys[i];
+            s_up[atomicAdd(&s_bin[hbin(kk)], 1)] = kk;      // s_bin[b]: first slot -> one past the last slot of bin b
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += 256) {
+            const unsigned long long kk = s_up[i];
+            const int b = hbin(kk);
+            const int lo = b ? s_bin[b - 1] : 0, hi = s_bin[b];
+            int r = lo;
+            for (int jj = lo; jj < hi; jj++) r += s_up[jj] < kk ? 1 : 0;
+            s_keys[r] = kk;
+        }
+    } else {
+        int np = 1;
+        while (np < n1) np <<= 1;
+        for (int i = n1 + tid; i < np; i += 256) s_keys[i] = ~0ull;
+        __syncthreads();
+        // bitonic sort, ascending on (~harris_order, y, x) == Harris descending, then y, then x
+        // Bitonic sort. Steps are taken two at a time: a thread loads the four keys (i, i+h, i+2h, i+3h) of a radix-4
+        // butterfly, does the compare-exchanges of step j = 2h and of step h in registers and stores them back -- one LDS
+        // round trip per two steps. (When a merge phase k has an odd number of steps its first one, j = k/2, goes alone, two
+        // pairs per thread, between workgroup barriers.) In butterfly steps a wave owns one aligned block of 256 keys; while
+        // consecutive butterflies stay inside it (span 2j <= 256) no workgroup barrier is needed -- the wave's LDS
+        // accesses are served in order.
+        auto steps_of = [](int kk) { int n = 0; for (int jj = kk >> 1; jj > 0; jj >>= 1) n++; return n; };
+        for (int k = 2; k <= np; k <<= 1) {
+            int j = k >> 1;
+            if (steps_of(k) & 1) {
+                __syncthreads();
+                for (int t0 = tid; t0 < (np >> 1); t0 += 512) {
+                    const int ta = t0, tb = t0 + 256;
+                    const bool hb = tb < (np >> 1);
+                    const int a0 = ((ta & ~(j - 1)) << 1) | (ta & (j - 1)), a1 = a0 | j;
+                    const int b0 = hb ? (((tb & ~(j - 1)) << 1) | (tb & (j - 1))) : a0, b1 = hb ? (b0 | j) : a1;
+                    const unsigned long long xa = s_keys[a0], ya = s_keys[a1], xb = s_keys[b0], yb = s_keys[b1];
+                    if ((xa > ya) == ((a0 & k) == 0)) { s_keys[a0] = ya; s_keys[a1] = xa; }
+                    if (hb && (xb > yb) == ((b0 & k) == 0)) { s_keys[b0] = yb; s_keys[b1] = xb; }
+                }
+                __syncthreads();
+                j >>= 1;
+            }
+            for (; j > 1; j >>= 2) {
+                const int h = j >> 1;
+                for (int t = tid; t < (np >> 2); t += 256) {
+                    const int i = ((t & ~(h - 1)) << 2) | (t & (h - 1));
+                    unsigned long long e0 = s_keys[i], e1 = s_keys[i + h], e2 = s_keys[i + j], e3 = s_keys[i + j + h];
+                    const bool up = (i & k) == 0;
+                    unsigned long long tmp;
+                    if ((e0 > e2) == up) { tmp = e0; e0 = e2; e2 = tmp; }       // step j
+                    if ((e1 > e3) == up) { tmp = e1; e1 = e3; e3 = tmp; }
+                    if ((e0 > e1) == up) { tmp = e0; e0 = e1; e1 = tmp; }       // step h
+                    if ((e2 > e3) == up) { tmp = e2; e2 = e3; e3 = tmp; }
+                    s_keys[i] = e0; s_keys[i + h] = e1; s_keys[i + j] = e2; s_keys[i + j + h] = e3;
+                }
+                // what follows: a butterfly with top step j/4 of this phase, or the next phase (a butterfly with top step k
+                // if it has an even number of steps; a single step syncs for itself)
+                const int next_span = (j >> 2) > 1 ? 2 * (j >> 2) : ((k < np && !(steps_of(2 * k) & 1)) ? 2 * k : 0);
+                if (2 * j > 256 || next_span > 256 || np > 1024) __syncthreads();   // np > 1024: a thread makes several trips
+                else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+            }
         }
     }
     __syncthreads();
@@ -929,6 +1023,7 @@ const EnvConfig& env_config() {
         c.level_streams = env_is("ARIA_LEVEL_STREAMS", '1') ? 1 : 0;
         c.stamp_level = env_int("ARIA_STAMPS", -1);
         c.sel_stamps = env_is("ARIA_SEL_STAMPS", '1') ? 1 : 0;
+        c.select_bitonic = env_is("ARIA_SELECT_SORT", 'b') ? 1 : 0;
         c.desc_stamps = env_is("ARIA_DESC_STAMPS", '1') ? 1 : 0;
         c.fast_blur_impl = env_is("ARIA_FAST_BLUR_IMPL", 't') ? 0 : env_is("ARIA_FAST_BLUR_IMPL", 'm') ? 1 : 2;
         c.pyr_impl = env_is("ARIA_PYRAMID_IMPL", 'f') ? 1 : 0;
@@ -1058,11 +1153,11 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     if (latency)
         ARIA_LAUNCH(prof, k_select<true>, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
                     st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items, D.ovf_keys,
-                    D.ovf_keys_cap, D.osel, D.osel_cap);
+                    D.ovf_keys_cap, D.osel, D.osel_cap, E.select_bitonic);
     else
         ARIA_LAUNCH(prof, k_select<false>, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
                     st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items, D.ovf_keys,
-                    D.ovf_keys_cap, D.osel, D.osel_cap);
+                    D.ovf_keys_cap, D.osel, D.osel_cap, E.select_bitonic);
     // tie-storm fallback: a fixed small grid that finds the work list empty on ordinary images
     if (!latency)
     ARIA_LAUNCH(prof, k_select_ovf, dim3(64), dim3(256), 0, st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err,
