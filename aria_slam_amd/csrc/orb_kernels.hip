@@ -372,7 +372,13 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
             const int b = hbin(kk);
             const int lo = b ? s_bin[b - 1] : 0, hi = s_bin[b];
             int r = lo;
-            for (int jj = lo; jj < hi; jj++) r += s_up[jj] < kk ? 1 : 0;
+            for (int j0 = lo; j0 < hi; j0 += 8) {       // eight independent LDS reads per trip (the reads past the bin's end
+                unsigned long long o[8];                 // stay inside the key array and are not counted)
+#pragma unroll
+                for (int u = 0; u < 8; u++) o[u] = s_up[min(j0 + u, hi - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) r += (j0 + u < hi && o[u] < kk) ? 1 : 0;
+            }
             s_keys[r] = kk;
         }
     } else {
