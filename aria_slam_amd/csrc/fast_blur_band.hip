@@ -128,7 +128,16 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     __shared__ int s_qn, s_ovf;
     // l_arg >= 0: this launch is level l_arg, blockIdx.x = strip. l_arg < 0 (single-frame latency schedule): ONE launch
     // covers every level -- blockIdx.x runs over the strips of all levels (ba.first = prefix sums), one strip per workgroup
-    int l = l_arg, strip = blockIdx.x, qcap = qcap_arg;
+    int l = l_arg, strip = blockIdx.x, qcap = qcap_arg, frame = blockIdx.y;
+    if (ba.xcd_map) {
+        // Workgroups go round-robin to the 8 XCDs (each with its own L2) by linear id. Neighbouring strips of a frame
+        // share 8 of their 21 staged rows, so all strips of a frame are given to ONE XCD (frame f -> XCD f mod 8): the
+        // shared rows then come from that XCD's L2 instead of HBM twice. Needs a frame count that is a multiple of 8.
+        const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x, j = b >> 3;
+        const uint32_t fq = __builtin_amdgcn_readfirstlane(j / gridDim.x);
+        strip = (int)(j - fq * gridDim.x);
+        frame = (int)(fq * 8u + (b & 7u));
+    }
     if (l_arg < 0) {
         l = 0;
 #pragma unroll
@@ -153,7 +162,6 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     uint32_t* s_queue = reinterpret_cast<uint32_t*>(smem + rowsL * pitchL);
 
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int frame = blockIdx.y;
     const int y0 = strip * RB;
     int pitch;
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
@@ -376,6 +384,10 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                 }
                 // y-table words of a batch of candidate rows are fetched together (one global round trip per 16 rows,
                 // not one per row)
+                // NB1 (rows in order, dy uniform in the wave): the horizontal blend of source row oy+1 is kept and serves as
+                // the TOP row of the next output row whenever that one starts at oy+1 (5 rows out of 6 at scale 1.2)
+                uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+                int hprev_row = -1;
                 for (int d0 = dlo + sb; d0 < dhi; d0 += 16 * nb) {
                 uint32_t tyv[16];
 #pragma unroll
@@ -389,21 +401,35 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                     uint32_t outw = 0;
                     if (dx0 < gn.w) {
                         const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
+                        const int rb = min(oy + 1, h - 1);
                         const uint8_t* rowa = s_pix + (oy - y0 + 4) * pitchL;
-                        const uint8_t* rowb = s_pix + (min(oy + 1, h - 1) - y0 + 4) * pitchL;
+                        const uint8_t* rowb = s_pix + (rb - y0 + 4) * pitchL;
+                        const bool reuse = NB1 && oy == hprev_row;       // wave-uniform
+                        uint32_t h0v[4];
+                        if (reuse) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) h0v[i] = hprev[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xo[i]);
+                                const uint32_t top = __builtin_amdgcn_perm(qa[1], qa[0], xs[i]);     // p00 | p01 << 16
+                                h0v[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, top), __builtin_bit_cast(us2v, xw[i]), 0u, false);
+                            }
+                        }
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xo[i]);
                             const uint32_t* qb = reinterpret_cast<const uint32_t*>(rowb + xo[i]);
-                            const uint32_t top = __builtin_amdgcn_perm(qa[1], qa[0], xs[i]);     // p00 | p01 << 16
                             const uint32_t bot = __builtin_amdgcn_perm(qb[1], qb[0], xs[i]);
                             const us2v wx = __builtin_bit_cast(us2v, xw[i]);
-                            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, top), wx, 0u, false);
+                            const uint32_t h0 = h0v[i];
                             const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, bot), wx, 0u, false);
                             const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, h0 | (h1 << 16)),
                                                                       __builtin_bit_cast(us2v, cyp), 32768u, false);   // < 2^24
                             outw = __builtin_amdgcn_perm(v, outw, put[i]);
+                            hprev[i] = h1;
                         }
+                        hprev_row = rb;
                     }
                     *reinterpret_cast<uint32_t*>(dstl + (int64_t)dy * gn.pitch + dx0) = outw;
                 }
@@ -616,9 +642,11 @@ static void band_launch_level(const Plan& P, const FrameSrc& S, const DeviceScra
     const int RB = c.nb * kBandR;
     const dim3 grid((g.h + RB - 1) / RB, n_frames);
     unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
+    BandAll ball{};
+    ball.xcd_map = (E.band_xcd_map && (n_frames & 7) == 0) ? 1 : 0;
 #define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
                                          D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1, D.tab, \
-                                         (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr, BandAll{})
+                                         (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr, ball)
     if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
     else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
 #undef ARIA_FB_LAUNCH

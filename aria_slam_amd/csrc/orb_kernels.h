@@ -76,6 +76,7 @@ struct EnvConfig {
     int level_streams;     // ARIA_LEVEL_STREAMS=1: one side stream per level
     int stamp_level;       // ARIA_STAMPS=<level>: phase stamps of the band kernel, -1 = off
     int sel_stamps;        // ARIA_SEL_STAMPS=1
+    int band_xcd_map;      // ARIA_BAND_XCD_MAP=0: plain (strip, frame) grid order in the batch FAST/blur launches
     int select_bitonic;    // ARIA_SELECT_SORT=bitonic: k_select always takes its LDS bitonic sort (default: histogram bins + in-bin ranks)
     int desc_stamps;       // ARIA_DESC_STAMPS=1
     int fast_blur_impl;    // 2 = band kernel, all VALU (fast_blur_band.hip, default), 1 = band kernel with the blur on the
@@ -126,7 +127,8 @@ int band_side_streams(LaunchCtx& ctx);   // create the per-level side streams + 
 
 // stand-alone pyramid pass (pyramid_pass.hip) and the tile form of the FAST/blur stage (fast_blur_tile.hip)
 // strips of all levels in one launch of the band kernel (single-frame latency schedule): first[l] = first blockIdx.x of level l
-struct BandAll { int first[kLevels + 1]; int qcap[kLevels]; };
+// xcd_map (per-level batch launches): 1 = the strips of a frame all go to one XCD (see k_fast_blur_band)
+struct BandAll { int first[kLevels + 1]; int qcap[kLevels]; int xcd_map; };
 bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof);
 void launch_pyramid_level(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof, int l);
 void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
