@@ -717,13 +717,24 @@ void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const Dev
     };
     const bool do_fork = fork && ctx.ev_fork && ctx.side[0];
     if (do_fork) {
+        // (the level-0 strips would race with the pyramid kernel's clearing: zero the counters before the fork as well)
+        hipMemsetAsync(D.ovf, 0, sizeof(int) * (size_t)(4 + kLevels * n_frames), st);
+        if (ctx.hdr) hipMemsetAsync(ctx.hdr, 0, 64, st);
         hipEventRecord(ctx.ev_fork, st);
         hipStreamWaitEvent(ctx.side[0], ctx.ev_fork, 0);
         band(0, 1, ctx.side[0]);
         hipEventRecord(ctx.ev_join[0], ctx.side[0]);
     }
-    if (!launch_pyramid_fused(P, S, D, n_frames, st, prof))
+    // the pass counters (arena + candidate counters, adjacent) and the single-frame result header are zeroed by the
+    // pyramid kernel's first workgroup; by fill nodes when the fused pyramid is not available for this plan
+    const int n_cnt = 4 + kLevels * n_frames;
+    const bool zc = latency_zero_copy(P, ctx, prof) && n_frames == 1;
+    if (!launch_pyramid_fused(P, S, D, n_frames, st, prof, D.ovf, n_cnt, ctx.hdr, ctx.hdr ? 16 : 0,
+                              zc ? ctx.host_img : nullptr, zc ? const_cast<uint8_t*>(S.img) : nullptr)) {
+        hipMemsetAsync(D.ovf, 0, sizeof(int) * (size_t)n_cnt, st);
+        if (ctx.hdr) hipMemsetAsync(ctx.hdr, 0, 64, st);
         for (int l = 1; l < kLevels; l++) launch_pyramid_level(P, S, D, n_frames, st, prof, l);
+    }
     band(do_fork ? 1 : 0, kLevels, st);
     if (do_fork) hipStreamWaitEvent(st, ctx.ev_join[0], 0);
 }

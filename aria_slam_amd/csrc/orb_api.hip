@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -61,6 +63,9 @@ struct aria_orb_s {
     Profiler prof;
     // single-frame latency path: the whole enqueue sequence (H2D, resize chain, 8 parallel FAST/blur branches, select,
     // describe, D2H) captured once per (plan, buffers) into a hipGraph and replayed
+    // ARIA_HOST_TIMING=1: host-side time of the single-frame entry points by segment (printed when the handle is destroyed)
+    double ht[4] = {0, 0, 0, 0};   // staging copy, enqueue/graph launch, wait, copy out
+    long ht_n = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_w = 0, graph_h = 0, graph_nf = 0, graph_cap = 0, graph_q = 0;
@@ -171,17 +176,27 @@ int ensure_plan(aria_orb_s* h, int w, int ht) {
 }
 
 int launch_single(aria_orb_s* h);
+static bool host_timing() { static const bool on = getenv("ARIA_HOST_TIMING") != nullptr; return on; }
 
 int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, int stride) {
     if (!image || stride < width) return ARIA_E_INVALID;
     int rc = ensure_plan(h, width, height);
     if (rc != ARIA_OK) return rc;
     const int pitch = align_up(width, 16);
-    for (int y = 0; y < height; y++) std::memcpy(h->h_img + (size_t)y * pitch, image + (size_t)y * stride, (size_t)width);
+    const bool timing = host_timing();
+    const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    if (stride == pitch) std::memcpy(h->h_img, image, (size_t)pitch * (height - 1) + (size_t)width);   // one call, not one per row
+    else for (int y = 0; y < height; y++) std::memcpy(h->h_img + (size_t)y * pitch, image + (size_t)y * stride, (size_t)width);
     FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1, (pitch % 16 == 0 && ((int64_t)pitch * height) % 16 == 0) ? 1 : 0};
     h->last_src = S;
     h->have_last = true;
-    return launch_single(h);
+    if (!timing) return launch_single(h);
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = launch_single(h);
+    const auto t2 = std::chrono::steady_clock::now();
+    h->ht[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    h->ht[1] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+    return rc;
 }
 
 // Internal single-frame output buffers (rows = kp_cap). A tie storm can return more keypoints than the plan's slots
@@ -214,6 +229,15 @@ int enqueue_single_ops(aria_orb_s* h);
 int launch_single(aria_orb_s* h) {
     static const bool want_graph = [] { const char* e = getenv("ARIA_SINGLE_GRAPH"); return !(e && e[0] == '0'); }();
     const bool diag = env_config().stamp_level >= 0 || env_config().sel_stamps || env_config().desc_stamps;
+    static const bool eager_latency = [] { const char* e = getenv("ARIA_SINGLE_GRAPH"); return e && e[0] == 'e'; }();
+    if (eager_latency && !h->prof.enabled && band_side_streams(h->ctx) == ARIA_OK) {
+        h->ctx.schedule = 1;            // ARIA_SINGLE_GRAPH=eager: the latency schedule's launches without the graph
+        return enqueue_single_ops(h);
+    }
+    if (diag && getenv("ARIA_DIAG_LATENCY") && band_side_streams(h->ctx) == ARIA_OK) {
+        h->ctx.schedule = 1;            // phase stamps of the latency schedule's kernels: same launches, eagerly
+        return enqueue_single_ops(h);
+    }
     if (!want_graph || h->graph_failed || h->prof.enabled || diag) { h->ctx.schedule = 0; return enqueue_single_ops(h); }
     if (band_side_streams(h->ctx) != ARIA_OK) { h->graph_failed = true; h->ctx.schedule = 0; return enqueue_single_ops(h); }
     const bool stale = !h->graph_exec || h->graph_w != h->plan.width || h->graph_h != h->plan.height ||
@@ -246,9 +270,13 @@ int launch_single(aria_orb_s* h) {
 
 int enqueue_single_ops(aria_orb_s* h) {
     const size_t img_bytes = (size_t)h->last_src.row_stride * h->plan.height;
-    ARIA_HIP(hipMemsetAsync(h->d_out, 0, 64, h->stream));        // count + the deferred error words of this frame
-    ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, h->stream));
+    h->ctx.hdr = reinterpret_cast<int*>(h->d_out);               // count + the deferred error words of this frame: zeroed by the pass
+    h->ctx.host_img = h->h_img;
+    if (!latency_zero_copy(h->plan, h->ctx, &h->prof))          // else the pyramid kernel pulls the frame from h_img itself
+        ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, h->stream));
     launch_extract_chunk(h->plan, h->last_src, h->D, 1, h->d_kps, h->d_desc, h->d_count, h->kp_cap, h->stream, &h->prof, h->ctx);
+    h->ctx.hdr = nullptr;
+    h->ctx.host_img = nullptr;
     ARIA_HIP(hipGetLastError());
     // the whole result in one copy: header (count, error words) + keypoints + descriptors
     ARIA_HIP(hipMemcpyAsync(h->h_out, h->d_out, 64 + (size_t)h->kp_cap * (sizeof(aria_keypoint) + 32), hipMemcpyDeviceToHost, h->stream));
@@ -256,7 +284,20 @@ int enqueue_single_ops(aria_orb_s* h) {
 }
 
 int finish_single(aria_orb_s* h, aria_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    const bool timing = host_timing();
+    const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     ARIA_HIP(hipStreamSynchronize(h->stream));
+    const auto t1 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    struct Acc {
+        aria_orb_s* h; bool on; std::chrono::steady_clock::time_point a, b;
+        ~Acc() {
+            if (!on) return;
+            const auto c = std::chrono::steady_clock::now();
+            h->ht[2] += std::chrono::duration<double, std::micro>(b - a).count();
+            h->ht[3] += std::chrono::duration<double, std::micro>(c - b).count();
+            h->ht_n++;
+        }
+    } acc{h, timing, t0, t1};
     if ((h->h_count[4] & ERRBIT_KPCAP) && h->h_count[6] > h->kp_cap) {
         // the frame has more keypoints than the internal buffers hold (ties): grow them and run the frame again
         // (its image is still in the handle's device copy)
@@ -361,6 +402,9 @@ void aria_orb_destroy(aria_orb_t h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->ht_n > 0)
+        fprintf(stderr, "[aria host timing] %ld single-frame calls, us per call: staging copy %.1f, enqueue %.1f, wait %.1f, copy out %.1f\n",
+                h->ht_n, h->ht[0] / h->ht_n, h->ht[1] / h->ht_n, h->ht[2] / h->ht_n, h->ht[3] / h->ht_n);
     h->prof.release();
     drop_graph(h);
     h->ctx.release();

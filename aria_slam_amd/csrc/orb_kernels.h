@@ -96,6 +96,14 @@ struct LaunchCtx {
     //    as parallel branches (side streams; captured into a hipGraph by orb_api.hip), because with one frame a level's
     //    launch is a handful of workgroups and the chain of 8 dependent launches is what the caller waits for
     int schedule = 0;
+    // single-frame host path: the 16-int result header (count, deferred error words) that launch_extract_chunk has to zero
+    // before the first kernel that writes it (nullptr: the caller's business). In the latency schedule the pyramid kernel
+    // does it together with the pass counters, which saves two fill nodes of the graph.
+    int* hdr = nullptr;
+    // single-frame latency schedule: the frame as it lies in the handle's pinned staging buffer. The pyramid kernel then
+    // reads level 0 from there (over the host link) and writes the device copy the later kernels use, so the graph has
+    // no upload node (latency_zero_copy() says whether launch_extract_chunk will take that route).
+    const uint8_t* host_img = nullptr;
     hipStream_t side[kLevels] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {}, ev_lvl[kLevels] = {};
     unsigned long long* d_band_stamps = nullptr;
@@ -129,7 +137,13 @@ int band_side_streams(LaunchCtx& ctx);   // create the per-level side streams + 
 // strips of all levels in one launch of the band kernel (single-frame latency schedule): first[l] = first blockIdx.x of level l
 // xcd_map (per-level batch launches): 1 = the strips of a frame all go to one XCD (see k_fast_blur_band)
 struct BandAll { int first[kLevels + 1]; int qcap[kLevels]; int xcd_map; };
-bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof);
+bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof,
+                          int* clr_a = nullptr, int n_a = 0, int* clr_b = nullptr, int n_b = 0,
+                          const uint8_t* src_alt = nullptr, uint8_t* copy_dst = nullptr);
+bool pyramid_fused_available(const Plan& P);
+// true when a single-frame pass with this context takes the latency schedule AND its pyramid kernel can pull the frame
+// from ctx.host_img itself (the caller then skips the upload)
+bool latency_zero_copy(const Plan& P, const LaunchCtx& ctx, const Profiler* prof);
 void launch_pyramid_level(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof, int l);
 void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
                                      Profiler* prof, LaunchCtx& ctx);

@@ -151,8 +151,12 @@ __device__ void select_ovf_item(const Plan& P, const FrameSrc& S, const uint8_t*
 
 // INLINE_OVF = false (batches): tie storms go to a work list and k_select_ovf. true (single-frame latency schedule: one
 // launch less): the overflowing workgroup runs the global-memory selection itself; ovf_items then carries the key arena.
-template <bool INLINE_OVF>
-__global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+// NT = threads per workgroup (the three prefix sums involve the first 256 threads only). 256 everywhere: 1024-thread
+// workgroups were tried for the single-frame latency schedule (8 workgroups on the whole chip) and lost -- the phases are
+// chains of dependent round trips, not trip counts (Harris 20k cycles in 2 rounds against 17k in 5), and with the inline
+// tie-storm path's scratch a 16-wave workgroup waits ~40k cycles before its first instruction (37 vs 25 us).
+template <bool INLINE_OVF, int NT>
+__global__ __launch_bounds__(NT) void k_select(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                 const uint32_t* __restrict__ cand, const int* __restrict__ cand_cnt,
                                                 uint4* __restrict__ sel, int* __restrict__ sel_cnt,
                                                 int* __restrict__ err, unsigned long long* __restrict__ stamps,
@@ -169,10 +173,11 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];   // P.sort_cap entries
     __shared__ int s_hist[256];
     __shared__ int s_misc[4];   // [0] threshold score, [1] n1, [2] n2
-    __shared__ int s_wsum[4];
+    __shared__ int s_wsum[NT / 64];
     __shared__ int s_bin[1024];   // keypoints per tile of the level
 
     const int tid = threadIdx.x;
+    const bool lead = tid < 256;          // (always true for NT = 256)
     const LevelGeom g = P.lv[l];
     const uint32_t* clist = cand + (int64_t)frame * P.cand_frame_entries + g.cand_off;
     const int n = min(cand_cnt[frame * kLevels + l], g.cand_cap);
@@ -183,22 +188,22 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         if (tid == 0) sel_cnt[frame * kLevels + l] = 0;
         return;
     }
-    s_hist[tid] = 0;
+    if (lead) s_hist[tid] = 0;
     if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0; }
     __syncthreads();
     // The candidate list is walked twice. Eight independent loads per lane and trip: a load-then-use loop pays one
     // global round trip per 256 candidates, which is what this kernel used to spend most of its time on.
     constexpr int kUnroll = 8;
-    for (int i0 = 0; i0 < n; i0 += 256 * kUnroll) {
+    for (int i0 = 0; i0 < n; i0 += NT * kUnroll) {
         uint32_t v[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            const int i = i0 + u * 256 + tid;
+            const int i = i0 + u * NT + tid;
             v[u] = i < n ? clist[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; u++)
-            if (i0 + u * 256 + tid < n) atomicAdd(&s_hist[v[u] >> 22], 1);
+            if (i0 + u * NT + tid < n) atomicAdd(&s_hist[v[u] >> 22], 1);
     }
     __syncthreads();
     SSTAMP(1);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     // + three wave totals through LDS. (A single lane walking the 256 bins cost every workgroup ~20k cycles.)
     {
         const int lane = tid & 63, wv = tid >> 6;
-        int c = s_hist[255 - tid];
+        int c = s_hist[255 - (tid & 255)];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(c, d);
@@ -222,23 +227,23 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         for (int w = 0; w < 3; w++)
             if (w < wv) before += s_wsum[w];
         const int cum = c + before;                                     // sum of hist[255 - tid ..255]
-        const int own = s_hist[255 - tid];
+        const int own = s_hist[255 - (tid & 255)];
         // exactly one thread sees the count cross 2q (if it crosses at all)
-        if (n > 2 * q && cum >= 2 * q && cum - own < 2 * q) s_misc[0] = 255 - tid;
+        if (lead && n > 2 * q && cum >= 2 * q && cum - own < 2 * q) s_misc[0] = 255 - tid;
         __syncthreads();
     }
     const int thr = s_misc[0];
     // survivors of the cut are first compacted into the key array (record in the low word) ...
-    for (int i0 = 0; i0 < n; i0 += 256 * kUnroll) {
+    for (int i0 = 0; i0 < n; i0 += NT * kUnroll) {
         uint32_t v[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            const int i = i0 + u * 256 + tid;
+            const int i = i0 + u * NT + tid;
             v[u] = i < n ? clist[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            const bool keep = i0 + u * 256 + tid < n && (int)(v[u] >> 22) >= thr;
+            const bool keep = i0 + u * NT + tid < n && (int)(v[u] >> 22) >= thr;
             const unsigned long long m = __ballot(keep);                // one LDS atomic per wave, not per survivor
             if (m) {
                 const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     const uint8_t* img = raw_level_ptr(P, S, raw, frame, l, pitch);
     {
         const int ns = min(s_misc[1], kSortCap);
-        for (int i = tid; i < ns; i += 256) {
+        for (int i = tid; i < ns; i += NT) {
             const uint32_t cd = (uint32_t)s_keys[i];
             const int x = cd & 0x7FF, y = (cd >> 11) & 0x7FF;
             const float r = harris_response(img, pitch, x, y, (l > 0) || S.aligned4);
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         // OpenCV's retainBest keeps them all, so this (frame, level) is redone by k_select_ovf in global memory.
         if (INLINE_OVF) {
             __shared__ __attribute__((aligned(8))) int s_ovm[8];
+            if (!lead) return;       // select_ovf_item is written for 256 threads; finished waves do not count at barriers
             select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l,
                             s_hist, s_ovm);
             return;
@@ -299,16 +305,16 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     __shared__ int s_srt[2];   // [0] bin of the cut, [1] largest kept bin
     auto hbin = [](unsigned long long kk) { return (int)min((uint32_t)(kk >> 53), 1023u); };
     const bool cut = n1 > q + 64;
-    for (int i = tid; i < 1024; i += 256) s_bin[i] = 0;
+    for (int i = tid; i < 1024; i += NT) s_bin[i] = 0;
     if (tid == 0) { s_srt[0] = 1023; s_srt[1] = 0; }
     __syncthreads();
-    for (int i = tid; i < n1; i += 256) atomicAdd(&s_bin[hbin(s_keys[i])], 1);
+    for (int i = tid; i < n1; i += NT) atomicAdd(&s_bin[hbin(s_keys[i])], 1);
     __syncthreads();
     {   // thread t owns bins 4t .. 4t+3: exclusive prefix sum (= first slot of every bin), bin where the count crosses q
         const int lane = tid & 63, wv = tid >> 6;
         int b[4], tot = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = s_bin[4 * tid + k]; tot += b[k]; }
+        for (int k = 0; k < 4; k++) { b[k] = lead ? s_bin[4 * tid + k] : 0; tot += b[k]; }
         int c = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -324,8 +330,8 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
             if (w < wv) run += s_wsum[w];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            s_bin[4 * tid + k] = run;
-            if (cut && run < q && run + b[k] >= q) s_srt[0] = 4 * tid + k;
+            if (lead) s_bin[4 * tid + k] = run;
+            if (lead && cut && run < q && run + b[k] >= q) s_srt[0] = 4 * tid + k;
             run += b[k];
         }
         __syncthreads();
@@ -333,14 +339,14 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         int mx = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (4 * tid + k <= bc) mx = max(mx, b[k]);
+            if (lead && 4 * tid + k <= bc) mx = max(mx, b[k]);
         if (mx > 0) atomicMax(&s_srt[1], mx);
     }
     const int bcut = s_srt[0];
     if (cut) {
         // in-place compaction of the kept keys to the front, 256 keys per round: a round's keys are in registers before
         // anyone writes (barrier), and writes only reach slots that this or an earlier round has consumed
-        for (int i0 = 0; i0 < n1; i0 += 256) {
+        for (int i0 = 0; i0 < n1; i0 += NT) {
             const int i = i0 + tid;
             const unsigned long long kk = i < n1 ? s_keys[i] : ~0ull;
             const bool keep = i < n1 && hbin(kk) <= bcut;
@@ -362,12 +368,12 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     const int upper = kSortCap >> 1;
     if (n1 <= upper && s_srt[1] <= 512 && !force_bitonic) {
         unsigned long long* s_up = s_keys + upper;
-        for (int i = tid; i < n1; i += 256) {
+        for (int i = tid; i < n1; i += NT) {
             const unsigned long long kk = s_keys[i];
             s_up[atomicAdd(&s_bin[hbin(kk)], 1)] = kk;      // s_bin[b]: first slot -> one past the last slot of bin b
         }
         __syncthreads();
-        for (int i = tid; i < n1; i += 256) {
+        for (int i = tid; i < n1; i += NT) {
             const unsigned long long kk = s_up[i];
             const int b = hbin(kk);
             const int lo = b ? s_bin[b - 1] : 0, hi = s_bin[b];
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     } else {
         int np = 1;
         while (np < n1) np <<= 1;
-        for (int i = n1 + tid; i < np; i += 256) s_keys[i] = ~0ull;
+        for (int i = n1 + tid; i < np; i += NT) s_keys[i] = ~0ull;
         __syncthreads();
         // bitonic sort, ascending on (~harris_order, y, x) == Harris descending, then y, then x
         // Bitonic sort. Steps are taken two at a time: a thread loads the four keys (i, i+h, i+2h, i+3h) of a radix-4
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
             int j = k >> 1;
             if (steps_of(k) & 1) {
                 __syncthreads();
-                for (int t0 = tid; t0 < (np >> 1); t0 += 512) {
-                    const int ta = t0, tb = t0 + 256;
+                for (int t0 = tid; t0 < (np >> 1); t0 += 2 * NT) {
+                    const int ta = t0, tb = t0 + NT;
                     const bool hb = tb < (np >> 1);
                     const int a0 = ((ta & ~(j - 1)) << 1) | (ta & (j - 1)), a1 = a0 | j;
                     const int b0 = hb ? (((tb & ~(j - 1)) << 1) | (tb & (j - 1))) : a0, b1 = hb ? (b0 | j) : a1;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
             }
             for (; j > 1; j >>= 2) {
                 const int h = j >> 1;
-                for (int t = tid; t < (np >> 2); t += 256) {
+                for (int t = tid; t < (np >> 2); t += NT) {
                     const int i = ((t & ~(h - 1)) << 2) | (t & (h - 1));
                     unsigned long long e0 = s_keys[i], e1 = s_keys[i + h], e2 = s_keys[i + j], e3 = s_keys[i + j + h];
                     const bool up = (i & k) == 0;
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
                 // what follows: a butterfly with top step j/4 of this phase, or the next phase (a butterfly with top step k
                 // if it has an even number of steps; a single step syncs for itself)
                 const int next_span = (j >> 2) > 1 ? 2 * (j >> 2) : ((k < np && !(steps_of(2 * k) & 1)) ? 2 * k : 0);
-                if (2 * j > 256 || next_span > 256 || np > 1024) __syncthreads();   // np > 1024: a thread makes several trips
+                if (2 * j > 256 || next_span > 256 || np > 4 * NT) __syncthreads();   // np > 4 NT: a thread makes several trips
                 else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
             }
         }
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     int n2 = n1;
     if (n1 > q) {
         const uint32_t cut = (uint32_t)(s_keys[q - 1] >> 32);
-        for (int i = q + tid; i < n1; i += 256)
+        for (int i = q + tid; i < n1; i += NT)
             if ((uint32_t)(s_keys[i] >> 32) == cut) atomicAdd(&s_misc[2], 1);
         __syncthreads();
         n2 = q + s_misc[2];
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     if (n2 > g.sel_cap) {      // more ties at the Harris cut than the level's slots hold: same fallback
         if (INLINE_OVF) {
             __shared__ __attribute__((aligned(8))) int s_ovm[8];
+            if (!lead) return;       // select_ovf_item is written for 256 threads; finished waves do not count at barriers
             select_ovf_item(P, S, raw, cand, cand_cnt, sel, sel_cnt, err, ovf, ovf_keys, ovf_keys_cap, osel, osel_cap, frame, l,
                             s_hist, s_ovm);
             return;
@@ -465,9 +472,9 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
     // 32-px tiles while the level has at most 1024 of them, else 64-px tiles
     const int ts = (((g.w + 31) >> 5) * ((g.h + 31) >> 5) <= 1024) ? 5 : 6;
     const int tiles_x = (g.w + (1 << ts) - 1) >> ts, n_bins = tiles_x * ((g.h + (1 << ts) - 1) >> ts);
-    for (int i = tid; i < n_bins; i += 256) s_bin[i] = 0;
+    for (int i = tid; i < n_bins; i += NT) s_bin[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += NT) {
         const uint32_t xy = (uint32_t)s_keys[i];
         atomicAdd(&s_bin[((xy >> (16 + ts)) * tiles_x) + ((xy & 0xFFFFu) >> ts)], 1);
     }
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
         const int lane = tid & 63, wv = tid >> 6;
         int b[4], tot = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (4 * tid + k < n_bins) ? s_bin[4 * tid + k] : 0; tot += b[k]; }
+        for (int k = 0; k < 4; k++) { b[k] = (lead && 4 * tid + k < n_bins) ? s_bin[4 * tid + k] : 0; tot += b[k]; }
         int c = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -492,12 +499,12 @@ __global__ __launch_bounds__(256) void k_select(Plan P, FrameSrc S, const uint8_
             if (w < wv) run += s_wsum[w];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (4 * tid + k < n_bins) s_bin[4 * tid + k] = run;
+            if (lead && 4 * tid + k < n_bins) s_bin[4 * tid + k] = run;
             run += b[k];
         }
     }
     __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += NT) {
         const unsigned long long kk = s_keys[i];
         uint32_t u = ~(uint32_t)(kk >> 32);
         u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
@@ -1088,9 +1095,9 @@ int LaunchCtx::init(int dev) {
     const EnvConfig& E = env_config();
     // kernels that may need more than the default 64 KB of dynamic LDS: the attribute belongs to (function, device),
     // so every handle sets it for its own device
-    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(sizeof(unsigned long long) * kSortCapMax)));
-    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_select<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(sizeof(unsigned long long) * kSortCapMax)));
     if (int prc = pyramid_set_attributes(); prc != ARIA_OK) return prc;
     int rc = band_set_attributes();
@@ -1117,19 +1124,34 @@ void LaunchCtx::release() {
     d_band_stamps = d_sel_stamps = d_desc_stamps = nullptr;
 }
 
+static bool latency_schedule(const LaunchCtx& ctx, const Profiler* prof) {
+    return ctx.schedule == 1 && ctx.ev_fork != nullptr && env_config().fast_blur_impl == 2 && !(prof && prof->enabled);
+}
+
+bool latency_zero_copy(const Plan& P, const LaunchCtx& ctx, const Profiler* prof) {
+    // opt-in (ARIA_ZERO_COPY=1): measured slower than the upload node, 128 vs 125 us per frame -- the band staging of the
+    // pyramid kernel turns into host-link round trips
+    static const bool off = [] { const char* e = getenv("ARIA_ZERO_COPY"); return !(e && e[0] == '1'); }();
+    const char* f = getenv("ARIA_LATENCY_FORK");        // (the forked level-0 launch reads the device copy at once)
+    return !off && !(f && f[0] == '1') && ctx.host_img != nullptr && latency_schedule(ctx, prof) && pyramid_fused_available(P);
+}
+
 void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames,
                           aria_keypoint* d_kps, uint8_t* d_desc, int* d_counts, int kp_cap, hipStream_t st,
                           Profiler* prof, LaunchCtx& ctx) {
     const EnvConfig& E = env_config();
     if (prof && prof->enabled) prof->frames += n_frames;
-    hipMemsetAsync(D.ovf, 0, sizeof(int) * (4 + kLevels * (size_t)n_frames), st);    // arena counters + candidate counters (adjacent)
 
     // ---- a6.1 pyramid ----
     // Default: no pass of its own -- the FAST/blur launch of level l writes the raw rows of level l+1 from the rows it
     // has staged (fast_blur_band.hip). A separate pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL,
     // ARIA_PYRAMID_IMPL) or when the band kernel is not the one in use (tile kernel, per-level side streams).
-    const bool latency = ctx.schedule == 1 && ctx.ev_fork != nullptr && E.fast_blur_impl == 2 && !(prof && prof->enabled);
+    const bool latency = latency_schedule(ctx, prof);
     const bool fuse_resize = E.fuse_resize != 0 && !latency;
+    if (!latency) {
+        hipMemsetAsync(D.ovf, 0, sizeof(int) * (4 + kLevels * (size_t)n_frames), st);    // arena counters + candidate counters (adjacent)
+        if (ctx.hdr) hipMemsetAsync(ctx.hdr, 0, 64, st);                                  // single-frame result header
+    }
     if (latency) {
         // single-frame latency schedule: resize chain and the 8 FAST/blur launches overlap (fast_blur_band.hip)
         launch_pyramid_and_band_latency(P, S, D, n_frames, st, prof, ctx);
@@ -1158,11 +1180,11 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;
     if (sstp) hipMemsetAsync(sstp, 0, sizeof(unsigned long long) * 8 * kLevels * (size_t)n_frames, st);
     if (latency)
-        ARIA_LAUNCH(prof, k_select<true>, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
+        ARIA_LAUNCH(prof, (k_select<true, 256>), dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
                     st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items, D.ovf_keys,
                     D.ovf_keys_cap, D.osel, D.osel_cap, E.select_bitonic);
     else
-        ARIA_LAUNCH(prof, k_select<false>, dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
+        ARIA_LAUNCH(prof, (k_select<false, 256>), dim3(kLevels, n_frames), dim3(256), sizeof(unsigned long long) * (size_t)P.sort_cap,
                     st, P, S, D.raw, D.cand, D.cand_cnt, D.sel, D.sel_cnt, D.err, sstp, D.ovf, D.ovf_items, D.ovf_keys,
                     D.ovf_keys_cap, D.osel, D.osel_cap, E.select_bitonic);
     // tie-storm fallback: a fixed small grid that finds the work list empty on ordinary images

@@ -272,10 +272,17 @@ __global__ __launch_bounds__(256) void k_resize_lds(Plan P, FrameSrc S, uint8_t*
 // just produced, and every row it owns goes to HBM exactly once. Nothing is re-read from HBM between levels, no item
 // waits on a global load, and the 7 dependent launches collapse into one.
 __global__ __launch_bounds__(256) void k_pyramid(Plan P, FrameSrc S, uint8_t* __restrict__ raw,
-                                                 const uint32_t* __restrict__ tab, const int* __restrict__ bands) {
+                                                 const uint32_t* __restrict__ tab, const int* __restrict__ bands,
+                                                 int* __restrict__ clr_a, int n_a, int* __restrict__ clr_b, int n_b,
+                                                 const uint8_t* __restrict__ src_alt, uint8_t* __restrict__ copy_dst) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_pyr[];
     const int tid = threadIdx.x;
     const int frame = blockIdx.y;
+    // single-frame latency schedule: this is the first kernel of the pass, the counters of the later ones are zeroed here
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < n_a) clr_a[tid] = 0;
+        if (tid < n_b) clr_b[tid] = 0;
+    }
     const int* B = bands + (int)blockIdx.x * kLevels * 4;
     uint32_t* s_xt = reinterpret_cast<uint32_t*>(smem_pyr + P.pyr_xtab_off);
     uint32_t* s_yt = reinterpret_cast<uint32_t*>(smem_pyr + P.pyr_ytab_off);
@@ -289,7 +296,11 @@ __global__ __launch_bounds__(256) void k_pyramid(Plan P, FrameSrc S, uint8_t* __
     }
     {
         const int lo0 = B[0], n0 = B[1], w0 = P.lv[0].w, p0 = P.pyr_p0;
-        const uint8_t* img = S.img + (int64_t)frame * S.frame_stride;
+        // src_alt (single-frame latency schedule): level 0 comes from the pinned host copy of the frame, and the rows this
+        // band owns are also written to the device copy (copy_dst) for the kernels that follow -- the upload rides along
+        const uint8_t* img = (src_alt ? src_alt : S.img) + (int64_t)frame * S.frame_stride;
+        uint8_t* cpy = copy_dst ? copy_dst + (int64_t)frame * S.frame_stride : nullptr;
+        const int own0 = B[3];
         uint8_t* d0 = smem_pyr + P.pyr_off[0];
         const int nch = S.aligned16 ? (w0 >> 4) : 0;
         if (nch > 0) {
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256) void k_pyramid(Plan P, FrameSrc S, uint8_t* __
                     for (int k = 0; k < 4; k++) {
                         const int r = r0 + k * rpp;
                         if (r < n0) *reinterpret_cast<uint4*>(d0 + r * p0 + 16 * my_c) = v[k];
+                        if (cpy && r < own0) *reinterpret_cast<uint4*>(cpy + (int64_t)(lo0 + r) * S.row_stride + 16 * my_c) = v[k];
                     }
                 }
             }
@@ -315,7 +327,9 @@ __global__ __launch_bounds__(256) void k_pyramid(Plan P, FrameSrc S, uint8_t* __
         const int ne = w0 - xe0;
         for (int i = tid; i < n0 * ne; i += 256) {
             const int r = i / ne, c = xe0 + (i - r * ne);
-            d0[r * p0 + c] = img[(int64_t)(lo0 + r) * S.row_stride + c];
+            const uint8_t px = img[(int64_t)(lo0 + r) * S.row_stride + c];
+            d0[r * p0 + c] = px;
+            if (cpy && r < own0) cpy[(int64_t)(lo0 + r) * S.row_stride + c] = px;
         }
     }
     __syncthreads();
@@ -383,9 +397,13 @@ int pyramid_set_attributes() {
 }
 
 // the whole pyramid in one launch (levels kept in LDS, bands of level-0 rows); false when its bands do not fit the LDS
-bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof) {
-    if (P.pyr_nbands <= 0 || P.pyr_lds_bytes > 150 * 1024) return false;
-    ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S, D.raw, D.tab, D.pyr_bands);
+bool pyramid_fused_available(const Plan& P) { return P.pyr_nbands > 0 && P.pyr_lds_bytes <= 150 * 1024; }
+
+bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof,
+                          int* clr_a, int n_a, int* clr_b, int n_b, const uint8_t* src_alt, uint8_t* copy_dst) {
+    if (!pyramid_fused_available(P) || n_a > 256 || n_b > 256) return false;
+    ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S, D.raw, D.tab, D.pyr_bands,
+                clr_a, n_a, clr_b, n_b, src_alt, copy_dst);
     return true;
 }
 
@@ -411,7 +429,7 @@ void launch_pyramid_pass(const Plan& P, const FrameSrc& S, const DeviceScratch& 
                                        // measured slower at 640x480: the top-down halo makes small bands recompute too much)
     if (pyr_impl == 1 && P.pyr_lds_bytes <= 150 * 1024) {
         ARIA_LAUNCH(prof, k_pyramid, dim3(P.pyr_nbands, n_frames), dim3(256), (size_t)P.pyr_lds_bytes, st, P, S,
-                    D.raw, D.tab, D.pyr_bands);
+                    D.raw, D.tab, D.pyr_bands, (int*)nullptr, 0, (int*)nullptr, 0, (const uint8_t*)nullptr, (uint8_t*)nullptr);
     } else {
         // 2 = LDS-staged bands with dot2 arithmetic (default), 1 = LDS-staged bands with shift/mad arithmetic
         // (ARIA_RESIZE_IMPL=lds), 0 = direct global gathers (ARIA_RESIZE_IMPL=direct)

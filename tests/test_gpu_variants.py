@@ -22,7 +22,9 @@ VARIANTS = [
     {"ARIA_BAND_QPCT0": "1", "ARIA_BAND_QPCT_STEP": "0"},          # survivor queue overflows -> slow path
     {"ARIA_BAND_BUDGET_KB": "160"},                                # several strips per workgroup
     {"ARIA_KNN_IMPL": "valu"},                                     # vector-ALU kNN-2 instead of the matrix-core one
-    {"ARIA_SELECT_SORT": "bitonic"},                               # k_select's LDS bitonic sort (fallback of the bin sort)
+    {"ARIA_SELECT_SORT": "bitonic"},
+    {"ARIA_ZERO_COPY": "1"},                                       # single-frame: pyramid kernel reads the pinned host frame itself
+    {"ARIA_BAND_XCD_MAP": "0"},                                    # plain (strip, frame) order of the batch FAST/blur workgroups                               # k_select's LDS bitonic sort (fallback of the bin sort)
 ]
 
 
