@@ -15,6 +15,13 @@ def _kp_bits(k):
 
 
 @pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
 def ext2000(aria):
     e = aria.OrbHipExtractor(max_features=2000, max_width=752, max_height=480)
     yield e
@@ -132,6 +139,50 @@ def test_match_train_resident_from_previous_call(aria, oracle):
             assert got.tobytes() == oracle.match_ratio(q, t, 0.75).tobytes()
     finally:
         m.close()
+
+
+def _noise(seed, w, h, lo, hi):
+    return np.random.default_rng(seed).integers(lo, hi, (h, w), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("kind,nf", [("noise", 1), ("noise", 7), ("noise", 120), ("noise", 2000), ("noise", 6000),
+                                     ("narrow", 500), ("narrow", 3000), ("synth", 9), ("synth", 4000)])
+def test_selection_orderings_bit_exact(aria, oracle, torch_cuda, kind, nf):
+    """k_select orders the Harris keys by histogram bins + in-bin ranks (bitonic sort when a bin is too full or the kept set
+    too large). Quotas from 1 to 6000, white noise (every pixel a FAST candidate: the largest key sets), low-contrast noise
+    (responses within a few octaves: few, full bins) and the synthetic frames, through the single-frame entry point AND
+    the batch entry point (two frames), against the oracle."""
+    torch = torch_cuda
+    w, h = 640, 480
+    if kind == "noise":
+        imgs = [_noise(100 + nf, w, h, 0, 256), _noise(200 + nf, w, h, 0, 256)]
+    elif kind == "narrow":
+        imgs = [_noise(300 + nf, w, h, 100, 160), _noise(400 + nf, w, h, 90, 170)]
+    else:
+        imgs = list(aria.synth_frame_pair(31, w, h))
+    p = oracle.default_params(nf)
+    want = [oracle.orb_extract(im, p) for im in imgs]
+    e = aria.OrbHipExtractor(max_features=nf, max_width=w, max_height=h, max_batch=2)
+    try:
+        for im, (kps, desc) in zip(imgs, want):
+            f = e.extract(im)
+            assert f["keypoints"].tobytes() == kps.tobytes(), "single-frame keypoints differ"
+            assert np.array_equal(f["descriptors"], desc)
+        cap = max(e.kp_capacity(), max(len(k) for k, _ in want))
+        dev = torch.device("cuda", 0)
+        d_img = torch.from_numpy(np.stack(imgs)).to(dev)
+        d_k = torch.zeros((2, cap, 24), dtype=torch.uint8, device=dev)
+        d_d = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+        d_c = torch.zeros((2,), dtype=torch.int32, device=dev)
+        e.extract_batch_device(d_img, 2, w, h, d_k, d_d, d_c, cap)
+        e.check()
+        c = d_c.cpu().numpy()
+        for i, (kps, desc) in enumerate(want):
+            assert c[i] == len(kps)
+            assert d_k.cpu().numpy()[i, :c[i]].tobytes() == kps.tobytes(), "batch keypoints differ"
+            assert np.array_equal(d_d.cpu().numpy()[i, :c[i]], desc)
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("w,h,nf", [(2047, 2047, 3000), (1919, 1083, 1500), (96, 2047, 200)])
