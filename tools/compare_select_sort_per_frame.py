@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# scratch: per-frame comparison of the default k_select ordering against ARIA_SELECT_SORT=bitonic on the bench sequence
+# per-frame comparison of the default k_select ordering against ARIA_SELECT_SORT=bitonic on the bench sequence
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

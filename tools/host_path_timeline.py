@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# scratch: print one steady-state iteration of tools/host_path_rate.py from a rocprofv3 rocpd database
+# print one steady-state iteration of tools/host_path_rate.py from a rocprofv3 rocpd database
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]

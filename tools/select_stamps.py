@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# scratch: k_select phase stamps (ARIA_SEL_STAMPS=1) for one frame at a time and for a 256-frame pass
+# k_select phase stamps (ARIA_SEL_STAMPS=1) for one frame at a time and for a 256-frame pass
 import os, sys
 os.environ["ARIA_SEL_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
