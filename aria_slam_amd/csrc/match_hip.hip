@@ -337,7 +337,7 @@ void launch_knn2(aria_matcher_s* m, int mode, int nq_max, int n_pairs, const uin
                  int maxq, double ratio, int* good, int max_train) {
     if (!m->knn_valu) {
         launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
-                         keys, maxq, ratio, good, max_train);
+                         keys, maxq, ratio, good, max_train, m->d_err + 1);
         return;
     }
     const dim3 grid((unsigned)((nq_max + 255) / 256), (unsigned)n_pairs);
@@ -376,8 +376,8 @@ void matcher_free(aria_matcher_s* m) {
 
 int matcher_alloc(aria_matcher_s* m) {
     const size_t nq = (size_t)std::max(m->max_query, 1), nt = (size_t)std::max(m->max_train, 1);
-    ARIA_HIP(hipMalloc(&m->d_err, sizeof(int)));
-    ARIA_HIP(hipMemset(m->d_err, 0, sizeof(int)));
+    ARIA_HIP(hipMalloc(&m->d_err, 2 * sizeof(int)));      // [0] deferred error bits, [1] narrow/wide gate of the batch kNN-2
+    ARIA_HIP(hipMemset(m->d_err, 0, 2 * sizeof(int)));
     ARIA_HIP(hipMalloc(&m->d_q, nq * 32));
     ARIA_HIP(hipMalloc(&m->d_t, nt * 32));
     ARIA_HIP(hipMalloc(&m->d_m, nq * sizeof(aria_match)));

@@ -12,7 +12,7 @@ namespace aria {
 // every pair's train count (selects the key layout).
 void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
                       const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
-                      uint2* keys, int maxq, double ratio, int* good, int max_train);
+                      uint2* keys, int maxq, double ratio, int* good, int max_train, int* gate = nullptr);
 
 // Latency schedule for ONE pair (frame-at-a-time host path): the train set is cut into nsplit slices of whole 64-train
 // tiles, every (query block, slice) is a workgroup, slice s writes keys[s * maxq + query] with GLOBAL train indices;

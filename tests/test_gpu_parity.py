@@ -116,6 +116,42 @@ def test_knn2_random_sets_with_ties(aria, oracle, nq, nt):
         m.close()
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_batch_match_rows_beyond_narrow_layout(aria, oracle, torch_cuda, big):
+    """Descriptor slots of 4160 rows (4000 features + slack) exceed the 12-bit train index of the narrow key layout, but
+    the layout is chosen on the device from the actual counts: all pairs <= 4096 -> the 512-query narrow kernel, one pair
+    above -> the wide kernel. 128 pairs (enough workgroups for the batch kernels); a few pairs against the oracle."""
+    torch = torch_cuda
+    dev = torch.device("cuda", 0)
+    rows, n_pairs = 4160, 128
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    desc = torch.randint(0, 256, (n_pairs + 1, rows, 32), dtype=torch.uint8, device=dev, generator=g)
+    desc[:, :, 8:] &= 0x0F                                   # low entropy: ties between train rows
+    cnt = torch.full((n_pairs + 1,), 4000, dtype=torch.int32, device=dev)
+    cnt[3] = 4096
+    cnt[7] = 1
+    if big:
+        cnt[5] = 4100
+    m = aria.HipMatcher(max_query=rows, max_train=rows)
+    try:
+        matches = torch.zeros((n_pairs, rows, 12), dtype=torch.uint8, device=dev)
+        nm = torch.zeros((n_pairs,), dtype=torch.int32, device=dev)
+        # pair p: query = slot p+1, train = slot p
+        m.match_batch_device(desc.data_ptr() + rows * 32, cnt.data_ptr() + 4, desc, cnt, n_pairs, rows * 32, 0.75, matches, nm, rows)
+        m.sync()
+        c = cnt.cpu().numpy()
+        for p in (0, 2, 3, 4, 5, 6, 7, n_pairs - 1):
+            q = desc[p + 1, :c[p + 1]].cpu().numpy()
+            t = desc[p, :c[p]].cpu().numpy()
+            want = oracle.match_ratio(q, t, 0.75)
+            n = int(nm[p].item())
+            assert n == len(want), "pair %d" % p
+            assert matches[p, :n].cpu().numpy().tobytes() == want.tobytes(), "pair %d" % p
+    finally:
+        m.close()
+
+
 def test_match_train_resident_from_previous_call(aria, oracle):
     """aria_matcher_match keeps the previous call's query set on the device and skips the train upload when the train
     bytes equal it (frame i against frame i-1). Hits, misses (other set, same size with one byte changed, other size)
