@@ -194,19 +194,20 @@ static int pyramid_bands_for(Plan* P, const uint32_t* tab, int bh, int* out, int
 }
 
 int build_pyramid_bands(Plan* P, const uint32_t* tab, int* out, int out_capacity) {
-    // Largest band height (multiple of 8) whose exact LDS footprint lets 3, else 2, else 1 workgroups share a CU.
-    // Note the halo: a band's deepest level needs one extra source row per level above it, amplified by 1.2 per
-    // level, so small bands recompute a lot; measured slower than per-level launches at 640x480.
-    const int budgets[3] = {53 * 1024, 80 * 1024, 150 * 1024};
+    // k_pyramid's default user is the single-frame latency schedule (one frame = one launch on an otherwise idle chip), so
+    // the bands are as thin as the table allows: 8 level-0 rows = 60 workgroups at 640x480, each a short chain of seven
+    // dependent levels (measured per aria_orb_extract: 8 rows 116.5 us, 12 rows 119.5, 24 rows -- the largest that lets
+    // three workgroups share a CU, the former choice -- 121-123). The halo (one extra source row per level, amplified by 1.2
+    // per level) makes thin bands recompute a lot, which is why the batch path does not use this kernel at all.
+    const int lds_max = 150 * 1024;
     if (const char* e = getenv("ARIA_PYR_BH")) {
         const int n = pyramid_bands_for(P, tab, std::max(8, atoi(e) & ~7), out, out_capacity);
-        if (n > 0 && P->pyr_lds_bytes <= budgets[2]) return n;
+        if (n > 0 && P->pyr_lds_bytes <= lds_max) return n;
     }
-    for (int bi = 0; bi < 3; bi++)
-        for (int bh = 64; bh >= 8; bh -= 8) {
-            const int n = pyramid_bands_for(P, tab, bh, out, out_capacity);
-            if (n > 0 && P->pyr_lds_bytes <= budgets[bi]) return n;
-        }
+    for (int bh = 8; bh <= 64; bh += 8) {
+        const int n = pyramid_bands_for(P, tab, bh, out, out_capacity);
+        if (n > 0 && P->pyr_lds_bytes <= lds_max) return n;
+    }
     return pyramid_bands_for(P, tab, 8, out, out_capacity);
 }
 
