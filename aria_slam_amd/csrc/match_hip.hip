@@ -159,17 +159,20 @@ __global__ __launch_bounds__(NT) void k_ratio_compact(const uint2* __restrict__ 
         uint2 k = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         if (qi < nq) {
             k = kk[qi];
-            // train slices of the latency schedule (one pair): two smallest of all; loads four at a time
-            for (int s0 = 1; s0 < nsplit; s0 += 4) {
-                uint2 o[4];
+            // train slices of the latency schedule (one pair): two smallest of all. All slices are requested before the
+            // first is merged (at most kKnnSplitMax - 1 loads in flight): on an idle chip every dependent round trip is a
+            // microsecond, and this kernel is on the frame-at-a-time path
+            if (nsplit > 1) {
+                uint2 o[kKnnSplitMax - 1];
 #pragma unroll
-                for (int j = 0; j < 4; j++) o[j] = kk[(int64_t)min(s0 + j, nsplit - 1) * maxq + qi];   // clamped loads past the last slice are not merged
+                for (int j = 0; j < kKnnSplitMax - 1; j++) o[j] = kk[(int64_t)min(1 + j, nsplit - 1) * maxq + qi];   // clamped loads past the last slice are not merged
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (s0 + j >= nsplit) break;
-                    const uint32_t lo = min(k.x, o[j].x);
-                    k.y = min(max(k.x, o[j].x), min(k.y, o[j].y));
-                    k.x = lo;
+                for (int j = 0; j < kKnnSplitMax - 1; j++) {
+                    if (1 + j < nsplit) {
+                        const uint32_t lo = min(k.x, o[j].x);
+                        k.y = min(max(k.x, o[j].x), min(k.y, o[j].y));
+                        k.x = lo;
+                    }
                 }
             }
             if (ratio == 0.0f) ok = k.x != 0xFFFFFFFFu;   // IMatcher.hpp:18 "0.0 = disabled"
