@@ -180,7 +180,10 @@ void aria_matcher_destroy(aria_matcher_t m);
  * first, as CPU cv::BFMatcher), then Lowe's test d0 < ratio*d1 in fp32 (CudaMatcher.cpp:60). Matches are
  * written in query order. nq == 0 or nt == 0 -> *n_out = 0 (CudaMatcher.cpp:35-37). nt == 1 -> no matches
  * (knn.size() >= 2 fails, :60). ratio == 0 means "ratio test disabled" as IMatcher.hpp:18 documents:
- * the best match of every query is returned (the reference adapter would return nothing). */
+ * the best match of every query is returned (the reference adapter would return nothing).
+ * Frame-to-frame use: the handle keeps the query set of the previous call on the device; when train_desc holds the
+ * same bytes (frame i matched against frame i-1) it is not uploaded again. Purely an optimisation -- the result never
+ * depends on it -- but it means a handle serves one caller at a time, like every other entry point here. */
 int aria_matcher_match(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* train_desc, int nt,
                float ratio, aria_match* matches, int cap, int* n_out);
 
