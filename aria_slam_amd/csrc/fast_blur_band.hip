@@ -235,7 +235,9 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
         }
         const uint32_t T2 = (uint32_t)thr * 0x00010001u;
         const int o_min = sb == 0 ? -1 : 0, o_max = sb == nb - 1 ? kBandR : kBandR - 1;
-        uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off + x;
+        // uniform base + 32-bit lane offset: the store takes the scalar-base form and the row address is one v_mad_u32_u24
+        // (a 64-bit per-lane pointer cost a v_mad_i64_i32 per output row)
+        uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
 
         const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
         const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
                             outw = __builtin_amdgcn_perm(min(r, 0x00FFFFFFu), outw, put[j]);
                         }
                         }
-                        *reinterpret_cast<uint32_t*>(bl + (int64_t)Y * g.pitch) = outw;
+                        *reinterpret_cast<uint32_t*>(bl + (uint32_t)(Y * g.pitch + x)) = outw;
                     }
                     // the ring rows (o = -1, o = R) are only this strip's job at the block's top / bottom edge;
                     // inside the block they are ordinary rows of the neighbouring strip
