@@ -759,8 +759,11 @@ __device__ __forceinline__ int row16_sum(int v) {
 // both in one launch -- the regular blocks, then kDescArenaBlocks blocks that stride over the arena (single-frame latency
 // schedule: one launch less; in a batch the extra code costs the regular blocks registers).
 constexpr int kDescArenaBlocks = 32;
+// (130 VGPRs = three waves per SIMD. Capping at 128 -- amdgpu_waves_per_eu(4), 120 used, no spills -- makes this stage 7 %
+// faster on its own, 0.96 -> 0.89 us/frame, but not the two-stream pipeline: 268.0-269.0k frames/s without the cap,
+// 266.3-269.1k with it, and the FAST/blur kernel beside the matcher then measures 0.160 instead of 0.163. Left uncapped.)
 template <int MODE>
-__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(4))) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint4* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int kp_cap,
