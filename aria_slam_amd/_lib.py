@@ -23,7 +23,7 @@ EXPORTS = [
     "aria_orb_default_config", "aria_orb_create", "aria_orb_destroy", "aria_orb_set_max_features",
     "aria_orb_get_max_features", "aria_orb_kp_capacity", "aria_orb_rows_needed", "aria_orb_fetch_last", "aria_orb_extract", "aria_orb_extract_async",
     "aria_orb_sync", "aria_orb_extract_batch_device", "aria_orb_check", "aria_orb_stream", "aria_orb_slow_path_blocks",
-    "aria_orb_set_profiling", "aria_orb_get_profile", "aria_matcher_set_profiling", "aria_matcher_get_profile",
+    "aria_orb_set_profiling", "aria_orb_set_stage_event", "aria_orb_get_profile", "aria_matcher_set_profiling", "aria_matcher_get_profile",
     "aria_orb_level_info", "aria_orb_resize_table", "aria_orb_pyramid_bands", "aria_orb_debug_read_level", "aria_orb_algorithmic_bytes",
     "aria_matcher_default_config", "aria_matcher_create", "aria_matcher_destroy", "aria_matcher_match",
     "aria_matcher_knn2", "aria_matcher_match_batch_device", "aria_matcher_match_db_device",
@@ -147,6 +147,7 @@ def load_library():
                                                            C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                            C.c_void_p, C.c_int, C.c_void_p]
     L.aria_orb_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.aria_orb_set_stage_event.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.aria_orb_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64)]
     L.aria_matcher_set_profiling.argtypes = [C.c_void_p, C.c_int]

@@ -495,8 +495,10 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
         const int nf = std::min(h->max_batch, n_frames - f0);
         FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4, aligned16};
         if (f0 == 0) { h->last_src = S; h->have_last = true; }
+        h->ctx.stage_events_armed = f0 + nf >= n_frames;      // aria_orb_set_stage_event: last pass only
         launch_extract_chunk(h->plan, S, h->D, nf, d_keypoints + (int64_t)f0 * kp_cap,
                              d_descriptors + (int64_t)f0 * kp_cap * 32, d_counts + f0, kp_cap, h->stream, &h->prof, h->ctx);
+        h->ctx.stage_events_armed = false;
     }
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
@@ -519,6 +521,13 @@ long long aria_orb_slow_path_blocks(aria_orb_t h, int reset) {
     const long long n = h->slow_blocks;
     if (reset) h->slow_blocks = 0;
     return n;
+}
+
+int aria_orb_set_stage_event(aria_orb_t h, int stage, void* event) {
+    if (!h || stage < 0 || stage >= ARIA_ORB_STAGES) return ARIA_E_INVALID;
+    if (stage != STAGE_SELECT) return ARIA_E_INVALID;       // the one point a caller has asked for so far
+    h->ctx.stage_event[stage] = static_cast<hipEvent_t>(event);
+    return ARIA_OK;
 }
 
 int aria_orb_set_profiling(aria_orb_t h, int enable) {

@@ -104,6 +104,10 @@ struct LaunchCtx {
     // reads level 0 from there (over the host link) and writes the device copy the later kernels use, so the graph has
     // no upload node (latency_zero_copy() says whether launch_extract_chunk will take that route).
     const uint8_t* host_img = nullptr;
+    // caller's events recorded on the stream right before a stage of a pass (aria_orb_set_stage_event); armed by the batch
+    // entry point for its last pass only
+    hipEvent_t stage_event[4] = {};
+    bool stage_events_armed = false;
     hipStream_t side[kLevels] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {}, ev_lvl[kLevels] = {};
     unsigned long long* d_band_stamps = nullptr;

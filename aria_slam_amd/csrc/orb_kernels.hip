@@ -1178,6 +1178,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     }
 
     // ---- a6.3-a6.5 selection ----
+    if (ctx.stage_events_armed && ctx.stage_event[STAGE_SELECT]) hipEventRecord(ctx.stage_event[STAGE_SELECT], st);
     if (prof) prof->begin(STAGE_SELECT, st);
     // diagnostic: ARIA_SEL_STAMPS=1 prints mean phase lengths per level
     unsigned long long* sstp = (ctx.d_sel_stamps && n_frames <= 4096) ? ctx.d_sel_stamps : nullptr;

@@ -137,6 +137,11 @@ class OrbHipExtractor:
 
     STAGES = ("resize", "fast_blur", "select", "describe")
 
+    def set_stage_event(self, stage, event_handle):
+        """Record `event_handle` (a raw hipEvent_t, e.g. torch.cuda.Event().cuda_event; None clears) on the stream right
+        before `stage` ("select") of the last pass of every batch call."""
+        check(self._L.aria_orb_set_stage_event(self._h, {"select": 2}[stage], event_handle), "aria_orb_set_stage_event")
+
     def set_profiling(self, enable, stages=None):
         """stages: optional subset of STAGES to bracket (each bracket drains the stream twice); default all."""
         v = int(bool(enable))

@@ -336,6 +336,10 @@ def main():
     ap.add_argument("--no-loop-closure", action="store_true", help="skip the untimed keyframe-DB exchange + scan leg")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="extractor and matcher on one stream (default: matcher of step s beside the extractor of step s+1)")
+    ap.add_argument("--match-beside", choices=["band", "select"], default="band",
+                    help="two-stream pipeline: the matcher of step s runs beside the FAST/blur launches of step s+1 (band: it "
+                         "starts as soon as step s is described) or beside select + describe of step s+1 (select: it also "
+                         "waits for the event the extractor records before its select stage, aria_orb_set_stage_event)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="extractor lanes: the per-GPU sequence is cut into this many contiguous parts, each with its own "
                          "extractor handle and stream, so that the VALU-bound FAST/blur launches of one part run beside the "
@@ -461,6 +465,30 @@ def main():
     halo_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
     halo_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
     step_no = [0]
+    beside_select = args.pipeline and args.match_beside == "select"
+    mid_ev = torch.cuda.Event()
+    pending = [None]              # --match-beside select: the set whose matching waits for the next extraction's mid event
+    if beside_select:
+        mid_ev.record(se)
+        ext.set_stage_event("select", mid_ev.cuda_event)
+
+    def enqueue_match(d, wait_mid=False):
+        with torch.cuda.stream(sm):
+            if args.pipeline:
+                for ev in d["described"]:
+                    sm.wait_event(ev)
+                if wait_mid:
+                    sm.wait_event(mid_ev)
+            mat.match_batch_device(d["desc"], d["counts"], halo_desc, halo_cnt, 1, dstride, args.ratio, d["matches"],
+                                   d["nmatches"], cap)
+            mat.match_batch_device(d["desc"].data_ptr() + dstride, d["counts"].data_ptr() + 4, d["desc"], d["counts"], B - 1,
+                                   dstride, args.ratio, d["matches"].data_ptr() + cap * 12, d["nmatches"].data_ptr() + 4, cap)
+            d["matched"].record(sm)
+
+    def flush_pending():
+        if pending[0] is not None:
+            enqueue_match(pending[0])
+            pending[0] = None
 
     def step(serialise=False):
         d = sets[step_no[0] % len(sets)]
@@ -481,15 +509,14 @@ def main():
             torch.cuda.synchronize(dev)
             for ev in d["described"][1:]:
                 ev.record(se)
-        with torch.cuda.stream(sm):
-            if args.pipeline:
-                for ev in d["described"]:
-                    sm.wait_event(ev)
-            mat.match_batch_device(d["desc"], d["counts"], halo_desc, halo_cnt, 1, dstride, args.ratio, d["matches"],
-                                   d["nmatches"], cap)
-            mat.match_batch_device(d["desc"].data_ptr() + dstride, d["counts"].data_ptr() + 4, d["desc"], d["counts"], B - 1,
-                                   dstride, args.ratio, d["matches"].data_ptr() + cap * 12, d["nmatches"].data_ptr() + 4, cap)
-            d["matched"].record(sm)
+        if beside_select and not serialise:
+            # this step's extraction is queued (its mid event recorded inside the call): now the PREVIOUS step's matching,
+            # held back until this extraction is past its FAST/blur launches
+            if pending[0] is not None:
+                enqueue_match(pending[0], wait_mid=True)
+            pending[0] = d
+        else:
+            enqueue_match(d)
         if serialise:
             torch.cuda.synchronize(dev)
         return d
@@ -509,6 +536,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    flush_pending()
     barrier()
     for e_ in exts:
         e_.check()
@@ -528,6 +556,7 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step()
+    flush_pending()               # (the last step's matching runs alone in either schedule)
     barrier()
     dt = time.perf_counter() - t0
     for e_ in exts:
@@ -682,7 +711,8 @@ def main():
                                             else ("bench.py --gpus N (launch_ranks)" if world > 1 else "single process"),
                        "rccl_ranks": rccl_ranks,
                        "streams": ("extractor and matcher on two streams, double-buffered outputs: the matcher of step s "
-                                   "runs beside the extractor of step s+1") if args.pipeline else "one stream",
+                                   "runs beside " + ("select + describe" if beside_select else "the FAST/blur launches") +
+                                   " of step s+1") if args.pipeline else "one stream",
                        "extractor_lanes": lanes,
                        "mean_keypoints_per_frame": round(float(cnt_host.mean()), 2),
                        "mean_matches_per_frame": round(float(nm_host.mean()), 2),

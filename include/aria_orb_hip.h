@@ -147,6 +147,14 @@ int aria_orb_set_profiling(aria_orb_t h, int enable);
 int aria_orb_get_profile(aria_orb_t h, int reset, double* stage_ms /*[4]*/, int64_t* stage_launches /*[4]*/,
                          int64_t* frames);
 
+/* Stream-ordering hook for callers that pipeline other work beside a batch extraction (no reference counterpart):
+ * `event` (a hipEvent_t, or NULL to clear) is recorded on the handle's stream right BEFORE stage `stage` (numbering as
+ * above) of the last internal pass of every aria_orb_extract_batch_device call. A second stream that waits on it starts
+ * when the FAST/blur launches are done -- bench.py lets the matcher of the previous step run beside select + describe
+ * rather than beside the FAST/blur kernel. Only stage 2 (select) is accepted so far (ARIA_E_INVALID otherwise). The
+ * event stays owned by the caller and must outlive the calls that record it. */
+int aria_orb_set_stage_event(aria_orb_t h, int stage, void* event);
+
 /* Introspection for parity tests and benchmarks (no reference counterpart).
  * Host-only geometry (no handle, no GPU needed): size, quota and scale of pyramid level `level` in [0, 8) for
  * a width x height image, as CPU cv::ORB lays it out; and the fixed-point INTER_LINEAR_EXACT coefficient table
