@@ -752,3 +752,39 @@ def test_dynamic_object_filter_on_device_equals_oracle(aria, oracle, torch_cuda,
     finally:
         e.close()
         m.close()
+
+
+def test_stage_event_is_recorded_before_select(aria, torch_cuda):
+    """aria_orb_set_stage_event: the caller's event is recorded on the handle's stream inside every batch call (before the
+    select stage of the last pass), a second stream waiting on it proceeds, results are unchanged; only stage 2 is accepted."""
+    torch = torch_cuda
+    dev = torch.device("cuda", 0)
+    W, H, NF, B = 640, 480, 1000, 5
+    seq = aria.synth_sequence(41, 3, W, H)[:B]
+    images = torch.from_numpy(seq).to(dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    e = aria.OrbHipExtractor(max_features=NF, stream=s1.cuda_stream, max_width=W, max_height=H, max_batch=2)   # three passes
+    try:
+        cap = e.kp_capacity()
+        out = [(torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                torch.zeros((B,), dtype=torch.int32, device=dev)) for _ in range(2)]
+        e.extract_batch_device(images, B, W, H, *out[0], cap)
+        ev = torch.cuda.Event()
+        ev.record(s1)
+        assert e._L.aria_orb_set_stage_event(e._h, 1, ev.cuda_event) == -1       # ARIA_E_INVALID: only the select stage
+        e.set_stage_event("select", ev.cuda_event)
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        e.extract_batch_device(images, B, W, H, *out[1], cap)
+        with torch.cuda.stream(s2):
+            s2.wait_event(ev)
+            flag += 1
+        torch.cuda.synchronize(dev)
+        e.check()
+        assert int(flag.item()) == 1
+        for a, b in zip(out[0], out[1]):
+            assert torch.equal(a, b)
+        e.set_stage_event("select", None)
+        e.extract_batch_device(images, B, W, H, *out[1], cap)
+        torch.cuda.synchronize(dev)
+    finally:
+        e.close()
