@@ -49,7 +49,10 @@ static BandCfg band_cfg(const Plan& P, int w, int level) {
     const int q0 = env_q0 >= 0 ? env_q0 : P.band_qpct0, qstep = env_qs >= 0 ? env_qs : P.band_qstep;
     const size_t budget = (size_t)budget_kb * 1024;
     const int qpct = std::min(50, q0 + qstep * level);
-    const int wq = (w + 3) & ~3, lpr = wq >> 2;
+    // lanes per row: one per 4-px column group. With blur_tie_mode 1 the last, partial group (w mod 4 columns) needs no lane:
+    // its blurred bytes are computed by the integer fix-up after the walk anyway, and it lies outside the FAST range (a
+    // level 257 px wide then takes 64 lanes, one full wave, instead of 65)
+    const int wq = (w + 3) & ~3, lpr = (P.tie_mode == 1 && (w & 3)) ? (w >> 2) : (wq >> 2);
     BandCfg best{};
     double best_util = -1.0;
     for (int nb = 1; nb <= 8; nb++) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     const LevelGeom g = P.lv[l];
     const int w = g.w, h = g.h;
     const int wq = (w + 3) & ~3;
-    const int lpr = wq >> 2;                             // lanes per row
+    const int lpr = (TIE_EVEN && (w & 3)) ? (w >> 2) : (wq >> 2);   // lanes per row (band_cfg: the partial last group has no lane)
     const int pitchL = wq + 8;                           // LDS pitch of the staged block: column 0 <-> x = -4
     const int sp = wq + 4;                               // score-map pitch: column 0 <-> x = -1
     const int RB = nb * kBandR;                          // output rows of this workgroup
@@ -698,7 +701,7 @@ void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const Dev
             if (l < l_lo || l >= l_hi) continue;        // no strips: blockIdx never maps to this level
             const LevelGeom& g = P.lv[l];
             // one strip per workgroup at every level (nb = 1): same code path, uniform block size = the widest level's
-            const int wq = (g.w + 3) & ~3, lpr = wq >> 2;
+            const int wq = (g.w + 3) & ~3, lpr = (P.tie_mode == 1 && (g.w & 3)) ? (g.w >> 2) : (wq >> 2);
             const int qpct = std::min(50, P.band_qpct0 + P.band_qstep * l);
             int qcap = (int)((int64_t)kBandR * wq * qpct / 100);
             qcap = std::max(512, (qcap + 63) & ~63);
