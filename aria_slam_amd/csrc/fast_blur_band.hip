@@ -34,6 +34,23 @@ constexpr int kBandR = 13;                 // output rows per strip: R + 8 = 21 
                                            // (12: 2.28, 13: 2.26, 20: 2.33, 32: 3.1 us/frame)
 constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a strip
 
+// Lanes per row of the walk for a level of width w: one per 4-px column group that some lane HAS to walk.
+//  * blur_tie_mode 1: the last, partial group (w mod 4 columns) needs no lane -- its blurred bytes are computed by the
+//    integer fix-up after the walk anyway, and it lies outside the FAST range (a 257-px level: 64 lanes, not 65);
+//  * blur_tie_mode 1, `trim`: the columns right of the FAST range (x > w - 31) are blur-only. When cutting at most 32 of
+//    them brings the lane count down to a whole number of waves, the walk stops there and the fix-up computes those
+//    columns too (a 533-px level: 128 lanes + 21 fix-up columns instead of 134 lanes in 192 threads).
+static int band_lanes(const Plan& P, int w, bool trim) {
+    const int wq = (w + 3) & ~3;
+    if (P.tie_mode != 1) return wq >> 2;
+    const int full = (w & 3) ? (w >> 2) : (wq >> 2);
+    if (!trim || w <= 2 * kEdgeThreshold) return full;
+    const int fast_lanes = ((w - kEdgeThreshold) >> 2) + 1;       // lanes whose columns reach into x <= w - 31
+    const int down = full & ~63;                                  // whole waves
+    if (down >= 64 && down >= fast_lanes && w - 4 * down <= 32 && down < full) return down;
+    return full;
+}
+
 // Workgroup geometry for a level of width w: NB vertically stacked strips of R rows share one staged block of
 // NB*R + 8 rows; thread = (strip, 4-px column). NB is chosen so the waves are full even on narrow levels.
 struct BandCfg { int nb, lpr, nthr, qcap; size_t lds; };
@@ -49,12 +66,17 @@ static BandCfg band_cfg(const Plan& P, int w, int level) {
     const int q0 = env_q0 >= 0 ? env_q0 : P.band_qpct0, qstep = env_qs >= 0 ? env_qs : P.band_qstep;
     const size_t budget = (size_t)budget_kb * 1024;
     const int qpct = std::min(50, q0 + qstep * level);
-    // lanes per row: one per 4-px column group. With blur_tie_mode 1 the last, partial group (w mod 4 columns) needs no lane:
-    // its blurred bytes are computed by the integer fix-up after the walk anyway, and it lies outside the FAST range (a
-    // level 257 px wide then takes 64 lanes, one full wave, instead of 65)
-    const int wq = (w + 3) & ~3, lpr = (P.tie_mode == 1 && (w & 3)) ? (w >> 2) : (wq >> 2);
+    const int wq = (w + 3) & ~3, lpr = band_lanes(P, w, false);
     BandCfg best{};
     double best_util = -1.0;
+    {   // one strip per workgroup with the lane count trimmed to whole waves, when the level allows it
+        const int lt = band_lanes(P, w, E.band_trim != 0);
+        if (lt < lpr) {
+            int qcap = (int)((int64_t)kBandR * wq * qpct / 100);
+            qcap = std::max(512, (qcap + 63) & ~63);
+            return BandCfg{1, lt, lt, qcap, (size_t)(kBandR + 8) * (wq + 8) + 4 * (size_t)qcap};
+        }
+    }
     for (int nb = 1; nb <= 8; nb++) {
         const int need = nb * lpr, nthr = ((need + 63) / 64) * 64;
         if (nthr > 512) break;
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     const LevelGeom g = P.lv[l];
     const int w = g.w, h = g.h;
     const int wq = (w + 3) & ~3;
-    const int lpr = (TIE_EVEN && (w & 3)) ? (w >> 2) : (wq >> 2);   // lanes per row (band_cfg: the partial last group has no lane)
+    const int lpr = ba.lpr[l];                           // lanes per row of the walk (band_lanes on the host)
     const int pitchL = wq + 8;                           // LDS pitch of the staged block: column 0 <-> x = -4
     const int sp = wq + 4;                               // score-map pitch: column 0 <-> x = -1
     const int RB = nb * kBandR;                          // output rows of this workgroup
@@ -449,22 +471,52 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     // ---- blur_tie_mode 1: OpenCV's SIMD column filter covers x < (w & ~3) (ties to even: what the fp32 column pass above
     //      computed); its scalar tail, the last w mod 4 columns, rounds ties UP. Those <= 3 columns per row are recomputed
     //      here in integers from the staged pixels (filter.simd.hpp SymmColumnFilter) and overwrite the bytes stored above. ----
-    if (TIE_EVEN && (w & 3) && !(ablate & 2)) {
-        const int nt = w & 3, xb = w & ~3;
+    // The same loop computes every column the walk left out (x >= 4 lpr: band_lanes' trimmed blur-only columns), with the
+    // SIMD path's round-half-to-even for x < (w & ~3).
+    if (TIE_EVEN && 4 * lpr < w && !(ablate & 2)) {
+        // thread -> (column, part of the block's rows): it walks its rows top to bottom with the seven horizontal sums of
+        // the window in registers, so a staged pixel is read once per column it contributes to (7 byte reads + the
+        // vertical pass per output pixel, not 49)
+        const int xb = 4 * lpr, nt = w - xb, x_even_end = w & ~3;
+        const int np = max(1, min(RB, 64 / nt));                 // row parts: one wave's worth of threads
+        const int rows_pp = (RB + np - 1) / np;
         uint8_t* blf = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
-        for (int i = tid; i < RB * nt; i += nthr) {
-            const int ro = i / nt, xx = xb + (i - ro * nt);
-            const int Y = y0 + ro;
-            if (Y >= h) continue;
-            uint32_t acc = 0;
+        if (nt <= 3) {
+            // the plain scalar tail: one (row, column) per thread, all 49 taps at once (independent loads: shortest chain)
+            for (int i = tid; i < RB * nt; i += nthr) {
+                const int ro = i / nt, xx = xb + (i - ro * nt);
+                const int Y = y0 + ro;
+                if (Y >= h) continue;
+                uint32_t acc = 0;
 #pragma unroll
-            for (int dy = 0; dy < 7; dy++) {
-                const uint8_t* p = s_pix + (ro + 1 + dy) * pitchL + (xx + 4);
-                const uint32_t hs = 18u * (p[-3] + p[3]) + 34u * (p[-2] + p[2]) + 49u * (p[-1] + p[1]) + 55u * p[0];
-                const uint32_t kv = dy == 0 || dy == 6 ? 18u : dy == 1 || dy == 5 ? 34u : dy == 2 || dy == 4 ? 49u : 55u;
-                acc += kv * hs;
+                for (int dy = 0; dy < 7; dy++) {
+                    const uint8_t* p = s_pix + (ro + 1 + dy) * pitchL + (xx + 4);
+                    const uint32_t hs = 18u * (p[-3] + p[3]) + 34u * (p[-2] + p[2]) + 49u * (p[-1] + p[1]) + 55u * p[0];
+                    const uint32_t kv = dy == 0 || dy == 6 ? 18u : dy == 1 || dy == 5 ? 34u : dy == 2 || dy == 4 ? 49u : 55u;
+                    acc += kv * hs;
+                }
+                const uint32_t bias = xx < x_even_end ? 0x7FFFu + ((acc >> 16) & 1u) : 0x8000u;
+                blf[(int64_t)Y * g.pitch + xx] = (uint8_t)min((acc + bias) >> 16, 255u);
             }
-            blf[(int64_t)Y * g.pitch + xx] = (uint8_t)min((acc + 0x8000u) >> 16, 255u);
+        } else if (tid < nt * np) {
+            const int part = tid / nt, xx = xb + (tid - part * nt);
+            const int r0 = part * rows_pp, r1 = min(RB, r0 + rows_pp);
+            uint32_t hsw[7] = {0, 0, 0, 0, 0, 0, 0};
+            const uint8_t* pc = s_pix + (xx + 4);
+            for (int k = r0 + 1; k < r1 + 7; k++) {              // staged rows; output row ro = k - 7 has its window complete
+                const uint8_t* p = pc + k * pitchL;
+                const uint32_t hs = 18u * (p[-3] + p[3]) + 34u * (p[-2] + p[2]) + 49u * (p[-1] + p[1]) + 55u * p[0];
+#pragma unroll
+                for (int u = 0; u < 6; u++) hsw[u] = hsw[u + 1];
+                hsw[6] = hs;
+                const int ro = k - 7, Y = y0 + ro;
+                if (ro >= r0 && Y < h) {
+                    const uint32_t acc = 18u * (hsw[0] + hsw[6]) + 34u * (hsw[1] + hsw[5]) + 49u * (hsw[2] + hsw[4]) + 55u * hsw[3];
+                    // ties up: + 0x8000; ties to even: + 0x7FFF + the quotient's low bit
+                    const uint32_t bias = xx < x_even_end ? 0x7FFFu + ((acc >> 16) & 1u) : 0x8000u;
+                    blf[(int64_t)Y * g.pitch + xx] = (uint8_t)min((acc + bias) >> 16, 255u);
+                }
+            }
         }
     }
 
@@ -649,6 +701,7 @@ static void band_launch_level(const Plan& P, const FrameSrc& S, const DeviceScra
     unsigned long long* stp = (l == stamp_level && (size_t)grid.x * grid.y <= 65536) ? d_stamps : nullptr;
     BandAll ball{};
     ball.xcd_map = (E.band_xcd_map && (n_frames & 7) == 0) ? 1 : 0;
+    ball.lpr[l] = c.lpr;
 #define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
                                          D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1, D.tab, \
                                          (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr, ball)
@@ -701,7 +754,8 @@ void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const Dev
             if (l < l_lo || l >= l_hi) continue;        // no strips: blockIdx never maps to this level
             const LevelGeom& g = P.lv[l];
             // one strip per workgroup at every level (nb = 1): same code path, uniform block size = the widest level's
-            const int wq = (g.w + 3) & ~3, lpr = (P.tie_mode == 1 && (g.w & 3)) ? (g.w >> 2) : (wq >> 2);
+            const int wq = (g.w + 3) & ~3, lpr = band_lanes(P, g.w, env_config().band_trim != 0);
+            ba.lpr[l] = lpr;
             const int qpct = std::min(50, P.band_qpct0 + P.band_qstep * l);
             int qcap = (int)((int64_t)kBandR * wq * qpct / 100);
             qcap = std::max(512, (qcap + 63) & ~63);

@@ -76,6 +76,7 @@ struct EnvConfig {
     int level_streams;     // ARIA_LEVEL_STREAMS=1: one side stream per level
     int stamp_level;       // ARIA_STAMPS=<level>: phase stamps of the band kernel, -1 = off
     int sel_stamps;        // ARIA_SEL_STAMPS=1
+    int band_trim;         // ARIA_BAND_TRIM=0: no trimming of blur-only right-edge columns to whole waves (band_lanes)
     int band_xcd_map;      // ARIA_BAND_XCD_MAP=0: plain (strip, frame) grid order in the batch FAST/blur launches
     int select_bitonic;    // ARIA_SELECT_SORT=bitonic: k_select always takes its LDS bitonic sort (default: histogram bins + in-bin ranks)
     int desc_stamps;       // ARIA_DESC_STAMPS=1
@@ -140,7 +141,8 @@ int band_side_streams(LaunchCtx& ctx);   // create the per-level side streams + 
 // stand-alone pyramid pass (pyramid_pass.hip) and the tile form of the FAST/blur stage (fast_blur_tile.hip)
 // strips of all levels in one launch of the band kernel (single-frame latency schedule): first[l] = first blockIdx.x of level l
 // xcd_map (per-level batch launches): 1 = the strips of a frame all go to one XCD (see k_fast_blur_band)
-struct BandAll { int first[kLevels + 1]; int qcap[kLevels]; int xcd_map; };
+// lpr[l]: lanes per row of level l in the walk (band_lanes(): the host decides, the kernel follows)
+struct BandAll { int first[kLevels + 1]; int qcap[kLevels]; int xcd_map; int lpr[kLevels]; };
 bool launch_pyramid_fused(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof,
                           int* clr_a = nullptr, int n_a = 0, int* clr_b = nullptr, int n_b = 0,
                           const uint8_t* src_alt = nullptr, uint8_t* copy_dst = nullptr);

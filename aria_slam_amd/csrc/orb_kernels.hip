@@ -1041,6 +1041,7 @@ const EnvConfig& env_config() {
         c.sel_stamps = env_is("ARIA_SEL_STAMPS", '1') ? 1 : 0;
         c.select_bitonic = env_is("ARIA_SELECT_SORT", 'b') ? 1 : 0;
         c.band_xcd_map = env_is("ARIA_BAND_XCD_MAP", '0') ? 0 : 1;
+        c.band_trim = env_is("ARIA_BAND_TRIM", '0') ? 0 : 1;
         c.desc_stamps = env_is("ARIA_DESC_STAMPS", '1') ? 1 : 0;
         c.fast_blur_impl = env_is("ARIA_FAST_BLUR_IMPL", 't') ? 0 : env_is("ARIA_FAST_BLUR_IMPL", 'm') ? 1 : 2;
         c.pyr_impl = env_is("ARIA_PYRAMID_IMPL", 'f') ? 1 : 0;
