@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# scratch: per-level duration of the batch FAST/blur launches from a rocprofv3 rocpd database
+# per-level duration of the batch FAST/blur launches from a rocprofv3 rocpd database
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1]); W = int(sys.argv[2]); H = int(sys.argv[3]); B = int(sys.argv[4])
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]

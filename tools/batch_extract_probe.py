@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# scratch: band kernel phase stamps (ARIA_STAMPS=<level>) for a batch of frames at a given size
+# band kernel phase stamps (ARIA_STAMPS=<level>) for a batch of frames at a given size
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
