@@ -30,6 +30,8 @@ EXPORTS = [
     "aria_matcher_stream", "aria_matcher_sync", "aria_synth_frame_pair", "aria_synth_sequence",
     "aria_flag_keypoints_device", "aria_matcher_match_batch_filtered_device", "aria_matcher_match_multi", "aria_matcher_count_good_multi", "aria_kfdb_create", "aria_kfdb_destroy", "aria_kfdb_size",
     "aria_kfdb_add", "aria_kfdb_add_device", "aria_kfdb_info", "aria_kfdb_fetch", "aria_kfdb_scan",
+    "aria_orb_last_device", "aria_matcher_match_device", "aria_matcher_retain_device", "aria_matcher_resident_rows",
+    "aria_matcher_match_device_async", "aria_matcher_finish", "aria_kfdb_match", "aria_stream_create", "aria_stream_destroy",
 ]
 
 
@@ -136,6 +138,14 @@ def load_library():
     L.aria_orb_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.aria_matcher_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_int)]
+    L.aria_orb_last_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.aria_matcher_match_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                            C.c_int, C.POINTER(C.c_int)]
+    L.aria_matcher_retain_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.aria_matcher_resident_rows.argtypes = [C.c_void_p]
+    L.aria_matcher_match_device_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.aria_matcher_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.aria_matcher_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.aria_matcher_match_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                   C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int]

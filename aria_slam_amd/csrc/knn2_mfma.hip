@@ -323,13 +323,13 @@ int knn2_split_count(int nq, int nt) {
 }
 
 void launch_knn2_mfma_split(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint2* keys, int maxq,
-                            int nsplit) {
+                            int nsplit, const int* nq_arr, const int* nt_arr) {
     if (nq <= 0 || nsplit <= 0) return;
     const int ntiles = (nt + 63) / 64, per = std::max(1, (ntiles + nsplit - 1) / nsplit);
     if (nt > kNarrowMax)
-        launch_one<0, true, 2, 64>(nq, 1, st, q, nullptr, nq, t, nullptr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
+        launch_one<0, true, 2, 64>(nq, 1, st, q, nq_arr, nq, t, nt_arr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
     else
-        launch_one<0, false, 2, 64>(nq, 1, st, q, nullptr, nq, t, nullptr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
+        launch_one<0, false, 2, 64>(nq, 1, st, q, nq_arr, nq, t, nt_arr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
 }
 
 }  // namespace aria

@@ -278,7 +278,10 @@ struct aria_matcher_s {
     uint8_t* d_pp[2] = {nullptr, nullptr};
     uint8_t* h_pp[2] = {nullptr, nullptr};
     int pp_n[2] = {-1, -1};
+    bool pp_host[2] = {false, false};   // h_pp[k] mirrors d_pp[k] (false: the set came from a device pointer)
     int pp_cur = 0;
+    // aria_matcher_match_device_async .. aria_matcher_finish: one pending operation
+    bool dev_pending = false;
     uint8_t* d_res = nullptr;       // [16 B header][max_query matches]
     uint8_t* h_res = nullptr;       // pinned
     // the four operations of aria_matcher_match as a hipGraph per ping-pong slot, keyed on the sizes; captured when a key
@@ -286,8 +289,9 @@ struct aria_matcher_s {
     struct MatchGraph {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        int nq = -1, nt = -1, hit = -1; float ratio = -1.f;              // key of exec
-        int seen_nq = -1, seen_nt = -1, seen_hit = -1; float seen_ratio = -1.f;
+        // key of exec: sizes, ratio, mode (MatchOps::mode) and the device pointers baked into the nodes
+        int nq = -1, nt = -1, hit = -1; float ratio = -1.f; const void* pa = nullptr; const void* pb = nullptr;
+        int seen_nq = -1, seen_nt = -1, seen_hit = -1; float seen_ratio = -1.f; const void* seen_pa = nullptr; const void* seen_pb = nullptr;
         void drop() {
             if (exec) hipGraphExecDestroy(exec);
             if (graph) hipGraphDestroy(graph);
@@ -355,6 +359,13 @@ void launch_knn2(aria_matcher_s* m, int mode, int nq_max, int n_pairs, const uin
 int ensure_keys(aria_matcher_s* m, size_t entries) {
     if (entries <= m->keys_cap) return ARIA_OK;
     ARIA_HIP(hipStreamSynchronize(m->stream));
+    // the captured single-pair graphs have the old d_keys pointer baked into their kernel nodes: drop them, and forget
+    // the "seen" keys so the next two calls capture afresh against the new buffer
+    for (auto& G : m->mg) {
+        G.drop();
+        G.seen_nq = G.seen_nt = G.seen_hit = -1;
+        G.seen_ratio = -1.f;
+    }
     if (m->d_keys) hipFree(m->d_keys);
     m->d_keys = nullptr;
     m->keys_cap = 0;
@@ -462,6 +473,28 @@ void aria_matcher_destroy(aria_matcher_t m) {
 
 void* aria_matcher_stream(aria_matcher_t m) { return m ? (void*)m->stream : nullptr; }
 
+// cudaStreamCreate / cudaStreamDestroy of the reference adapters (OrbCudaExtractor.cpp:28,50; CudaMatcher.cpp:16,24) for a
+// host that does not link the HIP runtime itself: one stream to hand to several handles so that their work is ordered.
+int aria_stream_create(int device, void** stream) {
+    if (!stream) return ARIA_E_INVALID;
+    *stream = nullptr;
+    int ndev = 0;
+    ARIA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return ARIA_E_NO_DEVICE;
+    ARIA_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    ARIA_HIP(hipStreamCreate(&s));
+    *stream = (void*)s;
+    return ARIA_OK;
+}
+int aria_stream_destroy(int device, void* stream) {
+    if (!stream) return ARIA_OK;
+    ARIA_HIP(hipSetDevice(device));
+    ARIA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    ARIA_HIP(hipStreamDestroy((hipStream_t)stream));
+    return ARIA_OK;
+}
+
 int aria_matcher_set_profiling(aria_matcher_t m, int enable) {
     if (!m) return ARIA_E_INVALID;
     m->prof_enabled = enable != 0;
@@ -493,59 +526,71 @@ int aria_matcher_sync(aria_matcher_t m) {
     return errbits_to_status(bits);
 }
 
-// The device work of one aria_matcher_match call on m->stream: upload of the query set into ping-pong slot cur (and of
-// the train set unless it is resident as the other slot), kNN-2 in train slices, ratio test + compaction with the
-// slice merge, one copy back ([count][matches]).
-static int enqueue_match_ops(aria_matcher_s* m, int cur, bool hit, int nq, int nt, float ratio) {
-    const uint8_t* d_train = m->d_pp[cur ^ 1];
-    if (!hit) {
-        ARIA_HIP(hipMemcpyAsync(m->d_t, m->h_stage, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-        d_train = m->d_t;
+// One single-pair match on m->stream, as aria_matcher_match / aria_matcher_match_device(_async) set it up. The NEW
+// descriptor set goes into ping-pong slot `cur` (from pinned host staging or from a device pointer) and stays resident for
+// the next call; the OTHER set is the resident slot cur ^ 1, an explicit device pointer, or (host path, no hit) an upload.
+struct MatchOps {
+    int cur = 0;
+    int mode = 0;                 // 0 host, other resident; 1 host, other uploaded; 2 device new + resident; 3 device new + explicit other
+    bool new_is_query = true;
+    int nq = 0, nt = 0;           // host-known sizes (upper bounds where a device count is given)
+    const uint8_t* d_new = nullptr;     // device source of the new set (modes 2, 3)
+    const uint8_t* d_other = nullptr;   // explicit other set (mode 3)
+    const int* d_n_new = nullptr;       // device row count of the new set (pipelined form), or nullptr = host-known
+    float ratio = 0.75f;
+};
+
+// kNN-2 in train slices, ratio test + compaction with the slice merge, one copy back ([count][matches]).
+static int enqueue_match_ops(aria_matcher_s* m, const MatchOps& o) {
+    const int cur = o.cur, n_new = o.new_is_query ? o.nq : o.nt;
+    const uint8_t* d_other = m->d_pp[cur ^ 1];
+    if (o.mode == 1) {
+        ARIA_HIP(hipMemcpyAsync(m->d_t, m->h_stage, (size_t)o.nt * 32, hipMemcpyHostToDevice, m->stream));
+        d_other = m->d_t;
+    } else if (o.mode == 3) {
+        d_other = o.d_other;
     }
-    ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], m->h_pp[cur], (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    if (o.mode <= 1) ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], m->h_pp[cur], (size_t)n_new * 32, hipMemcpyHostToDevice, m->stream));
+    else ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], o.d_new, (size_t)n_new * 32, hipMemcpyDeviceToDevice, m->stream));
+    const uint8_t* d_q = o.new_is_query ? m->d_pp[cur] : d_other;
+    const uint8_t* d_t = o.new_is_query ? d_other : m->d_pp[cur];
+    const int* nq_arr = o.new_is_query ? o.d_n_new : nullptr;
+    const int* nt_arr = o.new_is_query ? nullptr : o.d_n_new;
     int nsplit = 1;
     if (m->knn_valu) {
-        launch_knn2(m, 0, nq, 1, m->d_pp[cur], nullptr, nq, d_train, nullptr, nt, (int64_t)0, (int64_t)0, m->d_keys,
-                    m->max_query, 0.0, nullptr, nt);
+        launch_knn2(m, 0, o.nq, 1, d_q, nq_arr, o.nq, d_t, nt_arr, o.nt, (int64_t)0, (int64_t)0, m->d_keys, m->max_query, 0.0,
+                    nullptr, o.nt);
     } else {
-        nsplit = knn2_split_count(nq, nt);
-        launch_knn2_mfma_split(m->stream, m->d_pp[cur], nq, d_train, nt, m->d_keys, m->max_query, nsplit);
+        nsplit = knn2_split_count(o.nq, o.nt);
+        launch_knn2_mfma_split(m->stream, d_q, o.nq, d_t, o.nt, m->d_keys, m->max_query, nsplit, nq_arr, nt_arr);
     }
-    hipLaunchKernelGGL(k_ratio_compact<1024>, dim3(1), dim3(1024), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
+    hipLaunchKernelGGL(k_ratio_compact<1024>, dim3(1), dim3(1024), 0, m->stream, m->d_keys, nq_arr, o.nq, m->max_query, o.ratio,
                        reinterpret_cast<aria_match*>(m->d_res + 16), reinterpret_cast<int*>(m->d_res), m->max_query, m->d_err,
                        nullptr, nullptr, (int64_t)0, nullptr, nsplit);
     ARIA_HIP(hipGetLastError());
-    ARIA_HIP(hipMemcpyAsync(m->h_res, m->d_res, 16 + sizeof(aria_match) * (size_t)nq, hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipMemcpyAsync(m->h_res, m->d_res, 16 + sizeof(aria_match) * (size_t)o.nq, hipMemcpyDeviceToHost, m->stream));
     return ARIA_OK;
 }
 
-int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
-                       aria_match* matches, int cap, int* n_out) {
-    if (!m || !n_out || nq < 0 || nt < 0 || cap < 0) return ARIA_E_INVALID;
-    *n_out = 0;
-    if (nq == 0 || nt == 0) return ARIA_OK;   // CudaMatcher.cpp:35-37
-    if (!q || !t) return ARIA_E_INVALID;
-    if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
-    ARIA_HIP(hipSetDevice(m->device));
-    // train set = the query set of the previous call (frame i-1)? then it is on the device already
-    const int prev = m->pp_cur, cur = prev ^ 1;
-    const bool hit = m->pp_n[prev] == nt && nt <= m->max_query && std::memcmp(m->h_pp[prev], t, (size_t)nt * 32) == 0;
-    if (!hit) std::memcpy(m->h_stage, t, (size_t)nt * 32);
-    std::memcpy(m->h_pp[cur], q, (size_t)nq * 32);
-    m->pp_n[cur] = nq;
-    m->pp_cur = cur;
+// Replays the captured graph of these operations when the key (sizes, ratio, mode, baked-in pointers) repeats for the
+// slot; captures it when a key shows up the second time in a row; eager launches otherwise.
+static int launch_match_ops(aria_matcher_s* m, const MatchOps& o) {
     static const bool want_graph = [] { const char* e = getenv("ARIA_MATCH_GRAPH"); return !(e && e[0] == '0'); }();
-    aria_matcher_s::MatchGraph& G = m->mg[cur];
-    const int hit_i = hit ? 1 : 0;
-    if (want_graph && !m->graph_failed && G.exec && G.nq == nq && G.nt == nt && G.hit == hit_i && G.ratio == ratio) {
+    aria_matcher_s::MatchGraph& G = m->mg[o.cur];
+    const int mode_key = o.mode * 4 + (o.new_is_query ? 0 : 1) + (o.d_n_new ? 2 : 0);
+    const void* pa = o.d_new; const void* pb = o.d_n_new ? (const void*)o.d_n_new : (const void*)o.d_other;
+    const bool same = G.nq == o.nq && G.nt == o.nt && G.hit == mode_key && G.ratio == o.ratio && G.pa == pa && G.pb == pb;
+    const bool seen = G.seen_nq == o.nq && G.seen_nt == o.nt && G.seen_hit == mode_key && G.seen_ratio == o.ratio &&
+                      G.seen_pa == pa && G.seen_pb == pb;
+    if (want_graph && !m->graph_failed && G.exec && same) {
         ARIA_HIP(hipGraphLaunch(G.exec, m->stream));
-    } else if (want_graph && !m->graph_failed && G.seen_nq == nq && G.seen_nt == nt && G.seen_hit == hit_i && G.seen_ratio == ratio) {
+    } else if (want_graph && !m->graph_failed && seen) {
         G.drop();
         ARIA_HIP(hipStreamSynchronize(m->stream));
         hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
         int rc = ARIA_OK;
         if (e == hipSuccess) {
-            rc = enqueue_match_ops(m, cur, hit, nq, nt, ratio);
+            rc = enqueue_match_ops(m, o);
             e = hipStreamEndCapture(m->stream, &G.graph);
         }
         if (e == hipSuccess && rc == ARIA_OK) e = hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0);
@@ -553,18 +598,22 @@ int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t
             G.drop();
             (void)hipGetLastError();
             m->graph_failed = true;
-            rc = enqueue_match_ops(m, cur, hit, nq, nt, ratio);
+            rc = enqueue_match_ops(m, o);
             if (rc != ARIA_OK) return rc;
         } else {
-            G.nq = nq; G.nt = nt; G.hit = hit_i; G.ratio = ratio;
+            G.nq = o.nq; G.nt = o.nt; G.hit = mode_key; G.ratio = o.ratio; G.pa = pa; G.pb = pb;
             ARIA_HIP(hipGraphLaunch(G.exec, m->stream));
         }
     } else {
-        int rc = enqueue_match_ops(m, cur, hit, nq, nt, ratio);
+        int rc = enqueue_match_ops(m, o);
         if (rc != ARIA_OK) return rc;
     }
-    G.seen_nq = nq; G.seen_nt = nt; G.seen_hit = hit_i; G.seen_ratio = ratio;
-    ARIA_HIP(hipStreamSynchronize(m->stream));
+    G.seen_nq = o.nq; G.seen_nt = o.nt; G.seen_hit = mode_key; G.seen_ratio = o.ratio; G.seen_pa = pa; G.seen_pb = pb;
+    return ARIA_OK;
+}
+
+// stream is synchronised: hand the pinned result block to the caller
+static int fetch_match_result(aria_matcher_s* m, aria_match* matches, int cap, int* n_out) {
     const int n = reinterpret_cast<const int*>(m->h_res)[0];
     *n_out = n;
     if (n > cap) return ARIA_E_OUTPUT_TOO_SMALL;
@@ -573,6 +622,117 @@ int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t
         std::memcpy(matches, m->h_res + 16, sizeof(aria_match) * (size_t)n);
     }
     return ARIA_OK;
+}
+
+int aria_matcher_match(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
+                       aria_match* matches, int cap, int* n_out) {
+    if (!m || !n_out || nq < 0 || nt < 0 || cap < 0) return ARIA_E_INVALID;
+    *n_out = 0;
+    if (m->dev_pending) return ARIA_E_BUSY;
+    if (nq == 0 || nt == 0) return ARIA_OK;   // CudaMatcher.cpp:35-37
+    if (!q || !t) return ARIA_E_INVALID;
+    if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(m->device));
+    // train set = the query set of the previous call (frame i-1)? then it is on the device already
+    const int prev = m->pp_cur, cur = prev ^ 1;
+    const bool hit = m->pp_host[prev] && m->pp_n[prev] == nt && nt <= m->max_query &&
+                     std::memcmp(m->h_pp[prev], t, (size_t)nt * 32) == 0;
+    if (!hit) std::memcpy(m->h_stage, t, (size_t)nt * 32);
+    std::memcpy(m->h_pp[cur], q, (size_t)nq * 32);
+    m->pp_n[cur] = nq;
+    m->pp_host[cur] = true;
+    m->pp_cur = cur;
+    MatchOps o;
+    o.cur = cur; o.mode = hit ? 0 : 1; o.new_is_query = true; o.nq = nq; o.nt = nt; o.ratio = ratio;
+    int rc = launch_match_ops(m, o);
+    if (rc != ARIA_OK) return rc;
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    return fetch_match_result(m, matches, cap, n_out);
+}
+
+// ---- device-resident single-pair forms: the role CudaMatcher::matchGpu was declared for (CudaMatcher.hpp:22-28) ----
+static int match_device_setup(aria_matcher_s* m, const uint8_t* d_query, int nq, const uint8_t* d_train, int nt, float ratio,
+                              const int* d_n_new, MatchOps* out) {
+    if (m->dev_pending) return ARIA_E_BUSY;
+    if (!d_query && !d_train) return ARIA_E_INVALID;
+    if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
+    const int prev = m->pp_cur, cur = prev ^ 1;
+    MatchOps o;
+    o.cur = cur; o.nq = nq; o.nt = nt; o.ratio = ratio; o.d_n_new = d_n_new;
+    if (d_query && d_train) {            // both explicit: the query becomes the resident set
+        o.mode = 3; o.new_is_query = true; o.d_new = d_query; o.d_other = d_train;
+    } else {
+        o.mode = 2; o.new_is_query = d_query != nullptr; o.d_new = d_query ? d_query : d_train;
+        const int n_res = o.new_is_query ? nt : nq;
+        // with a device count the resident set's size is the caller's bound; otherwise it must be what is resident
+        if (m->pp_n[prev] < 0 || n_res != m->pp_n[prev]) return ARIA_E_INVALID;
+    }
+    const int n_new = o.new_is_query ? nq : nt;
+    if (n_new > m->max_query) return ARIA_E_TOO_LARGE;      // the ping-pong slots hold max_query rows
+    *out = o;
+    return ARIA_OK;
+}
+
+int aria_matcher_retain_device(aria_matcher_t m, const uint8_t* d_desc, int n) {
+    if (!m || n < 0 || (n > 0 && !d_desc)) return ARIA_E_INVALID;
+    if (m->dev_pending) return ARIA_E_BUSY;
+    if (n > m->max_query) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(m->device));
+    const int cur = m->pp_cur ^ 1;
+    if (n > 0) ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, m->stream));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    m->pp_n[cur] = n; m->pp_host[cur] = false; m->pp_cur = cur;
+    return ARIA_OK;
+}
+
+int aria_matcher_resident_rows(aria_matcher_t m) { return m ? m->pp_n[m->pp_cur] : ARIA_E_INVALID; }
+
+int aria_matcher_match_device(aria_matcher_t m, const uint8_t* d_query, int nq, const uint8_t* d_train, int nt, float ratio,
+                              aria_match* matches, int cap, int* n_out) {
+    if (!m || !n_out || nq < 0 || nt < 0 || cap < 0) return ARIA_E_INVALID;
+    *n_out = 0;
+    ARIA_HIP(hipSetDevice(m->device));
+    if (nq == 0 || nt == 0) {                 // CudaMatcher.cpp:35-37; the new set still becomes the resident one
+        const uint8_t* d_new = d_query ? d_query : d_train;
+        return aria_matcher_retain_device(m, d_new, d_query ? nq : nt);
+    }
+    MatchOps o;
+    int rc = match_device_setup(m, d_query, nq, d_train, nt, ratio, nullptr, &o);
+    if (rc != ARIA_OK) return rc;
+    m->pp_n[o.cur] = o.new_is_query ? nq : nt; m->pp_host[o.cur] = false; m->pp_cur = o.cur;
+    rc = launch_match_ops(m, o);
+    if (rc != ARIA_OK) return rc;
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    return fetch_match_result(m, matches, cap, n_out);
+}
+
+int aria_matcher_match_device_async(aria_matcher_t m, const uint8_t* d_new, const int* d_n_new, int n_new_max, int new_is_query,
+                                    float ratio) {
+    if (!m || !d_new || !d_n_new || n_new_max < 1) return ARIA_E_INVALID;
+    ARIA_HIP(hipSetDevice(m->device));
+    const int n_res = m->pp_n[m->pp_cur];
+    if (n_res < 1) return ARIA_E_INVALID;     // nothing resident to match against (aria_matcher_retain_device first)
+    MatchOps o;
+    int rc = match_device_setup(m, new_is_query ? d_new : nullptr, new_is_query ? n_new_max : n_res,
+                                new_is_query ? nullptr : d_new, new_is_query ? n_res : n_new_max, ratio, d_n_new, &o);
+    if (rc != ARIA_OK) return rc;
+    rc = launch_match_ops(m, o);
+    if (rc != ARIA_OK) return rc;
+    m->pp_n[o.cur] = -1; m->pp_host[o.cur] = false; m->pp_cur = o.cur;     // row count: told by aria_matcher_finish
+    m->dev_pending = true;
+    return ARIA_OK;
+}
+
+int aria_matcher_finish(aria_matcher_t m, int n_new, aria_match* matches, int cap, int* n_out) {
+    if (!m || !n_out || cap < 0 || n_new < 0) return ARIA_E_INVALID;
+    *n_out = 0;
+    if (!m->dev_pending) return ARIA_E_NOT_PENDING;
+    ARIA_HIP(hipSetDevice(m->device));
+    m->dev_pending = false;
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    m->pp_n[m->pp_cur] = n_new;
+    if (n_new == 0) return ARIA_OK;           // CudaMatcher.cpp:35-37 (the kernels saw a zero count and wrote no match)
+    return fetch_match_result(m, matches, cap, n_out);
 }
 
 int aria_matcher_knn2(aria_matcher_t m, const uint8_t* q, int nq, const uint8_t* t, int nt, int* idx, int* dist) {
@@ -862,6 +1022,31 @@ int aria_kfdb_fetch(aria_kfdb_t db, int index, uint8_t* desc, int cap_rows, int*
         ARIA_HIP(hipMemcpy(desc, db->d_desc + (size_t)slot * db->rows * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
     }
     return ARIA_OK;
+}
+
+// LoopClosureDetector::verifyGeometry's match list (src/legacy/LoopClosure.cpp:120-131): the query against keyframe
+// `index` where it lies in the database -- the keyframe's descriptors are neither downloaded nor uploaded again.
+int aria_kfdb_match(aria_kfdb_t db, aria_matcher_t m, int index, const uint8_t* q, int nq, float ratio, aria_match* matches,
+                    int cap, int* n_out) {
+    if (!db || !m || !n_out || index < 0 || index >= db->n || nq < 0 || cap < 0 || (nq > 0 && !q)) return ARIA_E_INVALID;
+    if (db->device != m->device) return ARIA_E_INVALID;
+    *n_out = 0;
+    if (m->dev_pending) return ARIA_E_BUSY;
+    const int slot = (db->head + index) % db->cap;
+    const int nt = db->counts[(size_t)slot];
+    if (nq == 0 || nt == 0) return ARIA_OK;                  // CudaMatcher.cpp:35-37
+    if (nq > m->max_query || nt > m->max_train) return ARIA_E_TOO_LARGE;
+    ARIA_HIP(hipSetDevice(db->device));
+    std::memcpy(m->h_stage, q, (size_t)nq * 32);
+    ARIA_HIP(hipMemcpyAsync(m->d_q, m->h_stage, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    launch_knn2(m, 0, nq, 1, m->d_q, nullptr, nq, db->d_desc + (size_t)slot * db->rows * 32, nullptr, nt, (int64_t)0, (int64_t)0,
+                m->d_keys, m->max_query, 0.0, nullptr, nt);
+    hipLaunchKernelGGL(k_ratio_compact<1024>, dim3(1), dim3(1024), 0, m->stream, m->d_keys, nullptr, nq, m->max_query, ratio,
+                       reinterpret_cast<aria_match*>(m->d_res + 16), reinterpret_cast<int*>(m->d_res), m->max_query, m->d_err);
+    ARIA_HIP(hipGetLastError());
+    ARIA_HIP(hipMemcpyAsync(m->h_res, m->d_res, 16 + sizeof(aria_match) * (size_t)nq, hipMemcpyDeviceToHost, m->stream));
+    ARIA_HIP(hipStreamSynchronize(m->stream));
+    return fetch_match_result(m, matches, cap, n_out);
 }
 
 int aria_kfdb_scan(aria_kfdb_t db, aria_matcher_t m, const uint8_t* q, int nq, double ratio, int* good, int cap, int* n_out) {

@@ -20,7 +20,9 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
 // 2000 x 2000 pair is 8 workgroups on 256 CUs otherwise. knn2_split_count picks nsplit (<= kKnnSplitMax).
 constexpr int kKnnSplitMax = 16;
 int knn2_split_count(int nq, int nt);
+// nq_arr / nt_arr (optional): device row counts of the query / train set (one int); nq / nt are then upper bounds that
+// size the grid and pick the key layout.
 void launch_knn2_mfma_split(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint2* keys, int maxq,
-                            int nsplit);
+                            int nsplit, const int* nq_arr = nullptr, const int* nt_arr = nullptr);
 
 }  // namespace aria

@@ -53,6 +53,9 @@ struct aria_orb_s {
     aria_keypoint* d_kps = nullptr;    // views into d_out / h_out
     uint8_t* d_desc = nullptr;
     int* d_count = nullptr;
+    int* d_err_single = nullptr;       // deferred error words of the single-frame path: header words 4.. of d_out
+    int* d_err_batch = nullptr;        // ... of the batch entry point: their own allocation, so that a single-frame call
+                                       // between a batch call and aria_orb_check cannot wipe the batch's deferred bits
     aria_keypoint* h_kps = nullptr;
     uint8_t* h_desc = nullptr;
     int* h_count = nullptr;            // = header of h_out
@@ -89,7 +92,8 @@ void free_scratch(aria_orb_s* h) {
     hipFree(h->D.raw); hipFree(h->D.blur); hipFree(h->D.cand);     // (D.cand_cnt lives behind D.ovf)
     hipFree(h->D.sel); hipFree(h->D.sel_cnt); hipFree(h->D.tab); hipFree(h->D.pyr_bands);    // (D.err lives inside d_out)
     hipFree(h->D.ovf); hipFree(h->D.ovf_items); hipFree(h->D.ovf_keys); hipFree(h->D.osel);
-    hipFree(h->d_img); hipFree(h->d_out);
+    hipFree(h->d_img); hipFree(h->d_out); hipFree(h->d_err_batch);
+    h->d_err_batch = nullptr; h->d_err_single = nullptr;
     if (h->h_img) hipHostFree(h->h_img);
     if (h->h_out) hipHostFree(h->h_out);
     h->d_out = nullptr; h->h_out = nullptr;
@@ -133,7 +137,7 @@ int alloc_scratch(aria_orb_s* h) {
     h->bands_host.assign((size_t)((h->max_h + 7) / 8) * kLevels * 4 + 64, 0);
     ARIA_HIP(hipMalloc(&h->D.pyr_bands, sizeof(int) * h->bands_host.size()));
     // D.err ([0] deferred error bits, [1] band-kernel slow-path blocks, [2] rows needed by the largest frame that did not
-    // fit kp_cap) is part of the single-frame output block: alloc_io below
+    // fit kp_cap): part of the single-frame output block for that path (alloc_io below), d_err_batch for batches
     // tie-storm arenas: room for the worst case of four whole frames per pass (every FAST candidate of every level tied)
     {
         long long per_frame = 0;
@@ -149,6 +153,8 @@ int alloc_scratch(aria_orb_s* h) {
     ARIA_HIP(hipHostMalloc(&h->h_img, img_bytes));
     rc = alloc_io(h, h->kp_cap);
     if (rc != ARIA_OK) return rc;
+    ARIA_HIP(hipMalloc(&h->d_err_batch, 4 * sizeof(int)));
+    ARIA_HIP(hipMemset(h->d_err_batch, 0, 4 * sizeof(int)));
     h->plan_valid = false;
     return ARIA_OK;
 }
@@ -213,7 +219,8 @@ int alloc_io(aria_orb_s* h, int rows) {
     ARIA_HIP(hipMemset(h->d_out, 0, 64));
     std::memset(h->h_out, 0, 64);
     h->d_count = reinterpret_cast<int*>(h->d_out);
-    h->D.err = reinterpret_cast<int*>(h->d_out) + 4;
+    h->d_err_single = reinterpret_cast<int*>(h->d_out) + 4;
+    h->D.err = h->d_err_single;
     h->d_kps = reinterpret_cast<aria_keypoint*>(h->d_out + 64);
     h->d_desc = h->d_out + 64 + (size_t)rows * sizeof(aria_keypoint);
     h->h_count = reinterpret_cast<int*>(h->h_out);
@@ -271,6 +278,7 @@ int launch_single(aria_orb_s* h) {
 int enqueue_single_ops(aria_orb_s* h) {
     const size_t img_bytes = (size_t)h->last_src.row_stride * h->plan.height;
     h->ctx.hdr = reinterpret_cast<int*>(h->d_out);               // count + the deferred error words of this frame: zeroed by the pass
+    h->D.err = h->d_err_single;
     h->ctx.host_img = h->h_img;
     if (!latency_zero_copy(h->plan, h->ctx, &h->prof))          // else the pyramid kernel pulls the frame from h_img itself
         ARIA_HIP(hipMemcpyAsync(h->d_img, h->h_img, img_bytes, hipMemcpyHostToDevice, h->stream));
@@ -478,6 +486,20 @@ int aria_orb_fetch_last(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descrip
     return ARIA_OK;
 }
 
+// The role OrbCudaExtractor::getGpuDescriptors() plays (include/adapters/gpu/OrbCudaExtractor.hpp:34-35): where the
+// single-frame result lies on the device.
+int aria_orb_last_device(aria_orb_t h, const aria_keypoint** d_keypoints, const uint8_t** d_descriptors, const int** d_count,
+                         int* n, int* rows) {
+    if (!h) return ARIA_E_INVALID;
+    if (!h->d_out) return ARIA_E_NOT_PENDING;
+    if (d_keypoints) *d_keypoints = h->d_kps;
+    if (d_descriptors) *d_descriptors = h->d_desc;
+    if (d_count) *d_count = h->d_count;
+    if (n) *n = h->pending ? -1 : h->last_n;
+    if (rows) *rows = h->kp_cap;
+    return ARIA_OK;
+}
+
 int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_frames, int width, int height,
                                   int64_t frame_stride, int row_stride, aria_keypoint* d_keypoints,
                                   uint8_t* d_descriptors, int* d_counts, int kp_cap) {
@@ -491,6 +513,7 @@ int aria_orb_extract_batch_device(aria_orb_t h, const uint8_t* d_images, int n_f
     const int aligned4 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 3) == 0;
     const int aligned16 = (((uintptr_t)d_images | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15) == 0;
     h->ctx.schedule = 0;        // batches use the throughput schedule
+    h->D.err = h->d_err_batch;
     for (int f0 = 0; f0 < n_frames; f0 += h->max_batch) {
         const int nf = std::min(h->max_batch, n_frames - f0);
         FrameSrc S{d_images + (int64_t)f0 * frame_stride, frame_stride, row_stride, aligned4, aligned16};
@@ -509,8 +532,8 @@ int aria_orb_check(aria_orb_t h) {
     ARIA_HIP(hipSetDevice(h->device));
     ARIA_HIP(hipStreamSynchronize(h->stream));
     int two[4] = {0, 0, 0, 0};
-    ARIA_HIP(hipMemcpy(two, h->D.err, 4 * sizeof(int), hipMemcpyDeviceToHost));
-    if (two[0] || two[1] || two[2]) ARIA_HIP(hipMemset(h->D.err, 0, 4 * sizeof(int)));
+    ARIA_HIP(hipMemcpy(two, h->d_err_batch, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (two[0] || two[1] || two[2]) ARIA_HIP(hipMemset(h->d_err_batch, 0, 4 * sizeof(int)));
     h->rows_needed = two[2];
     note_slow_blocks(h, two[1]);
     return errbits_to_status(two[0]);

@@ -113,7 +113,17 @@ class OrbHipExtractor:
     def getMaxFeatures(self):
         return self._L.aria_orb_get_max_features(self._h)
 
-    # ---- device-resident batch form (OrbCudaExtractor::getGpuDescriptors' role) ----
+    # ---- OrbCudaExtractor::getGpuDescriptors (include/adapters/gpu/OrbCudaExtractor.hpp:34-35) ----
+    def device_result(self):
+        """(d_keypoints, d_descriptors, d_count, n, rows): raw device pointers of the single-frame result block, the host
+        copy of the count (-1 while an async extract is pending) and the block's row capacity."""
+        kp, ds, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, rows = C.c_int(), C.c_int()
+        check(self._L.aria_orb_last_device(self._h, C.byref(kp), C.byref(ds), C.byref(cnt), C.byref(n), C.byref(rows)),
+              "aria_orb_last_device")
+        return kp.value, ds.value, cnt.value, n.value, rows.value
+
+    # ---- device-resident batch form ----
     def kp_capacity(self):
         return self._L.aria_orb_kp_capacity(self._h)
 
@@ -246,7 +256,32 @@ class HipMatcher:
                                         idx.ctypes.data, dist.ctypes.data), "aria_matcher_knn2")
         return idx, dist
 
-    # ---- device-resident forms (CudaMatcher::matchGpu's role) ----
+    # ---- CudaMatcher::matchGpu (include/adapters/gpu/CudaMatcher.hpp:22-28): descriptors on the device ----
+    def match_device(self, d_query, nq, d_train, nt, ratio_threshold=0.75):
+        """d_query / d_train: raw device pointers (int) or None = the set kept resident from the previous call."""
+        out = np.empty(max(nq, 1), MATCH_DTYPE)
+        n = C.c_int()
+        check(self._L.aria_matcher_match_device(self._h, _ptr(d_query), nq, _ptr(d_train), nt, C.c_float(ratio_threshold),
+                                                out.ctypes.data, len(out), C.byref(n)), "aria_matcher_match_device")
+        return out[:n.value].copy()
+
+    def retain_device(self, d_desc, n):
+        check(self._L.aria_matcher_retain_device(self._h, _ptr(d_desc), n), "aria_matcher_retain_device")
+
+    def resident_rows(self):
+        return self._L.aria_matcher_resident_rows(self._h)
+
+    def match_device_async(self, d_new, d_n_new, n_new_max, new_is_query=True, ratio_threshold=0.75):
+        check(self._L.aria_matcher_match_device_async(self._h, _ptr(d_new), _ptr(d_n_new), n_new_max, int(bool(new_is_query)),
+                                                      C.c_float(ratio_threshold)), "aria_matcher_match_device_async")
+
+    def finish(self, n_new, cap):
+        out = np.empty(max(cap, 1), MATCH_DTYPE)
+        n = C.c_int()
+        check(self._L.aria_matcher_finish(self._h, n_new, out.ctypes.data, len(out), C.byref(n)), "aria_matcher_finish")
+        return out[:n.value].copy()
+
+    # ---- device-resident batch forms ----
     def match_batch_device(self, d_query, d_nq, d_train, d_nt, n_pairs, desc_stride, ratio, d_matches, d_nmatches,
                            match_cap):
         check(self._L.aria_matcher_match_batch_device(self._h, _ptr(d_query), _ptr(d_nq), _ptr(d_train), _ptr(d_nt),

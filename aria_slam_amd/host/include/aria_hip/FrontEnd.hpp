@@ -29,6 +29,12 @@ struct FrontEndConfig {
     // detection of a dynamic class are dropped, as the legacy executable does (src/main.cpp:29-50, 164-175). The detector is
     // not part of this repository: its boxes for the current frame arrive through FrontEnd::setDetections().
     bool filter_dynamic_objects = true;
+    // When the injected pair is OrbHipExtractor + HipMatcher on one device, the descriptors stay on the device between the
+    // two calls -- the getGpuDescriptors() / matchGpu hand-off the reference declares (OrbCudaExtractor.hpp:34-35,
+    // CudaMatcher.hpp:22-28): no descriptor upload per frame. If both were also constructed on the SAME stream
+    // (factory::createHip does that) the match is queued behind extractAsync and one wait covers both (the async shape of
+    // docs/milestones/H12_CLEAN_ARCHITECTURE.md:711-716). Results are identical either way; false = always the host port calls.
+    bool device_handoff = true;
 };
 
 // COCO ids of src/main.cpp:29-40: person, bicycle, car, motorcycle, bus, train, truck, bird, cat, dog
@@ -61,8 +67,14 @@ public:
     interfaces::IFeatureExtractor& extractor() { return *extractor_; }
     interfaces::IMatcher& matcher() { return *matcher_; }
     interfaces::ILoopDetector* loopDetector() { return loop_detector_.get(); }
+    // Something that must outlive the components (factory::createHip: the stream they share); released last.
+    void setKeepAlive(std::shared_ptr<void> k) { keep_alive_ = std::move(k); }
+    // 0: host port calls, 1: device hand-off (two waits), 2: device hand-off queued behind extractAsync (one wait)
+    int handoffMode() const { return handoff_mode_; }
 
 private:
+    void extractAndMatch(const std::uint8_t* image_data, int width, int height, core::Frame& f);
+    std::shared_ptr<void> keep_alive_;            // declared first: destroyed after the components below
     interfaces::FeatureExtractorPtr extractor_;
     interfaces::MatcherPtr matcher_;
     interfaces::LoopDetectorPtr loop_detector_;
@@ -72,6 +84,7 @@ private:
     FrontEndResult result_;
     std::function<void(const FrontEndResult&)> callback_;
     std::uint64_t next_id_ = 0;
+    int handoff_mode_ = 0;
 };
 
 }  // namespace aria::pipeline

@@ -15,7 +15,8 @@ namespace aria::factory {
 struct HipFactoryConfig {
     int hip_device = 0;            // FactoryConfig::cuda_device (PipelineFactory.hpp:24)
     int max_features = 1000;       // FactoryConfig::max_features (:27)
-    void* stream = nullptr;        // borrowed hipStream_t shared by the three components, or nullptr
+    void* stream = nullptr;        // borrowed hipStream_t shared by the three components, or nullptr: createHip() then makes
+                                   // one stream for extractor + matcher (and keeps it alive as long as the FrontEnd)
     pipeline::FrontEndConfig frontend;
     bool enable_loop_closure = true;        // PipelineConfig::enable_loop_closure (SlamPipeline.hpp:17)
     int loop_min_frames_between = 200;      // src/euroc_eval.cpp:103
@@ -27,6 +28,8 @@ struct HipComponents {
     interfaces::FeatureExtractorPtr extractor;
     interfaces::MatcherPtr matcher;
     interfaces::LoopDetectorPtr loop_detector;      // null when loop closure is disabled
+    std::shared_ptr<void> shared_stream;            // owner of the stream made for the components (empty: caller's stream or
+                                                    // none); must be released after them
 };
 
 HipComponents createHipComponents(const HipFactoryConfig& cfg);

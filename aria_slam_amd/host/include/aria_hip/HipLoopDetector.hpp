@@ -10,7 +10,8 @@
 // verification step. The reference's verification is geometric (essential-matrix RANSAC in OpenCV, :116-190), which is
 // outside the feature front-end: here a candidate is accepted when its ratio-0.7 match list has at least min_matches
 // entries (the same bound verifyGeometry applies to its inliers), unless the caller installs a verifier (setVerifier),
-// which receives both keyframes and the match list and may reject or fill in the relative pose.
+// which receives the query keyframe, the matched keyframe's id and the candidate (match list filled) and may reject it or fill in
+// the relative pose.
 #pragma once
 #include <functional>
 #include <optional>
@@ -46,8 +47,10 @@ public:
     int size() const;
     std::uint64_t keyframeId(int index) const;
 
-    using Verifier = std::function<bool(const core::KeyFrame& query, std::uint64_t match_id, std::vector<core::Match>& matches,
-                                        double relative_pose[16])>;
+    // May reject the candidate (return false) or refine it: candidate.matches holds the ratio-0.7 match list on entry,
+    // candidate.relative_pose is the verifier's to fill in (Eigen::Matrix4d in the reference's core/Types.hpp:120; the
+    // candidate is passed whole so that this header does not have to name that type).
+    using Verifier = std::function<bool(const core::KeyFrame& query, std::uint64_t match_id, core::LoopCandidate& candidate)>;
     void setVerifier(Verifier v) { verifier_ = std::move(v); }
 
 private:
@@ -60,6 +63,7 @@ private:
     int loop_count_ = 0;
     Verifier verifier_;
     std::vector<int> good_;
+    std::vector<core::Match> match_buf_;
 };
 
 }  // namespace aria::adapters::hip

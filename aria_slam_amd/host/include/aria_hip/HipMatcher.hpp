@@ -35,7 +35,24 @@ public:
                                                           const std::vector<core::Frame>& keyframes,
                                                           int min_frames_between);
 
+    // CudaMatcher::matchGpu (include/adapters/gpu/CudaMatcher.hpp:22-28, "GPU-to-GPU matching, zero-copy when used with
+    // OrbCudaExtractor"): descriptor sets given as device pointers (OrbHipExtractor::deviceResult()), matches appended on
+    // the host. The matcher keeps ONE set resident on the device between calls; nullptr for d_query or d_train stands for
+    // it (its row count must then be nq / nt). Afterwards the resident set is the non-null one (the query if both are
+    // given): frame i against frame i-1 needs no descriptor upload at all.
+    void matchDevice(const std::uint8_t* d_query, int nq, const std::uint8_t* d_train, int nt, std::vector<core::Match>& matches,
+                     float ratio_threshold = 0.75f);
+    void retainDevice(const std::uint8_t* d_desc, int n);      // make a set resident without matching (first frame)
+    int residentRows() const;                                   // -1: nothing resident
+    // Pipelined form, for an extractor and a matcher constructed on the SAME stream: queue the match of the new set
+    // (row count read on the device from *d_count, at most rows_max) against the resident set behind the extraction, then
+    // finishDevice() once the frame's keypoint count is known. Returns false (nothing queued) when nothing is resident.
+    bool matchDeviceAsync(const std::uint8_t* d_new, const int* d_count, int rows_max, bool new_is_query, float ratio_threshold = 0.75f);
+    void finishDevice(int n_new, std::vector<core::Match>& matches);
+
     aria_matcher_s* handle() const { return m_; }
+    void* streamArg() const { return stream_; }
+    int device() const { return device_; }
     void reserve(int nq, int nt) { ensure(nq, nt); }       // creates / grows the C handle
 
 private:

@@ -26,9 +26,26 @@ public:
     void setMaxFeatures(int n) override;
     int getMaxFeatures() const override { return max_features_; }
 
-    // The C handle, for callers that want the device-resident batch entry points (the role getGpuDescriptors()
-    // was meant to play, OrbCudaExtractor.hpp:35).
+    // OrbCudaExtractor::getGpuDescriptors() (include/adapters/gpu/OrbCudaExtractor.hpp:34-35, "get descriptors without
+    // download (for GPU matching)"): where the result of the last extract / extractAsync lies on the device, for
+    // HipMatcher::matchDevice*. The pointers stay the same from frame to frame; `count` is the device copy of the keypoint
+    // count (what work queued behind extractAsync on the same stream reads), `n` the host copy (-1 while pending), `rows`
+    // the block's row capacity. All null before the first extraction.
+    struct DeviceResult {
+        const core::KeyPoint* keypoints = nullptr;
+        const std::uint8_t* descriptors = nullptr;
+        const int* count = nullptr;
+        int n = -1, rows = 0;
+    };
+    DeviceResult deviceResult() const;
+    // creates (or grows) the C handle for images up to width x height, so that deviceResult()'s pointers exist before the
+    // first extractAsync
+    void reserve(int width, int height) { ensure(width, height); }
+
+    // The C handle, for callers that want the device-resident batch entry points.
     aria_orb_s* handle() const { return h_; }
+    void* streamArg() const { return stream_; }      // the stream given to the constructor (nullptr = own stream)
+    int device() const { return device_; }
 
 private:
     void ensure(int width, int height);

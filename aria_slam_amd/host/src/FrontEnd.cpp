@@ -4,6 +4,9 @@
 #include <stdexcept>
 #include <utility>
 
+#include "aria_hip/HipMatcher.hpp"
+#include "aria_hip/OrbHipExtractor.hpp"
+
 namespace aria::pipeline {
 
 bool isDynamicClass(int class_id) {                        // src/main.cpp:29-40
@@ -24,6 +27,65 @@ bool inDynamicObject(const core::KeyPoint& kp, const std::vector<core::Detection
 FrontEnd::FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::MatcherPtr matcher, const FrontEndConfig& cfg)
     : extractor_(std::move(extractor)), matcher_(std::move(matcher)), cfg_(cfg) {
     if (!extractor_ || !matcher_) throw std::invalid_argument("FrontEnd: extractor and matcher must not be null");
+    auto* hx = dynamic_cast<adapters::hip::OrbHipExtractor*>(extractor_.get());
+    auto* hm = dynamic_cast<adapters::hip::HipMatcher*>(matcher_.get());
+    if (cfg_.device_handoff && hx && hm && hx->device() == hm->device())
+        handoff_mode_ = (hx->streamArg() && hx->streamArg() == hm->streamArg()) ? 2 : 1;
+}
+
+// extract + match of one frame. Host port calls in general; with the HIP pair the descriptors are handed over on the
+// device (see FrontEndConfig::device_handoff) -- the matcher keeps the previous frame's set resident.
+void FrontEnd::extractAndMatch(const std::uint8_t* image_data, int width, int height, core::Frame& f) {
+    const bool have_prev = cur_ != nullptr;             // cur_ still is the previous frame here
+    if (handoff_mode_ == 0) {
+        extractor_->extract(image_data, width, height, f);            // H12_CLEAN_ARCHITECTURE.md:597
+        if (have_prev) {
+            if (cfg_.legacy_order) matcher_->match(*cur_, f, result_.matches, cfg_.ratio_threshold);   // euroc_eval.cpp:168-169
+            else matcher_->match(f, *cur_, result_.matches, cfg_.ratio_threshold);                      // H12...:601
+        }
+        return;
+    }
+    auto& hx = static_cast<adapters::hip::OrbHipExtractor&>(*extractor_);
+    auto& hm = static_cast<adapters::hip::HipMatcher&>(*matcher_);
+    const int n_prev = have_prev ? (int)cur_->numKeypoints() : 0;
+    bool queued = false;
+    adapters::hip::OrbHipExtractor::DeviceResult before;
+    if (handoff_mode_ == 2) {
+        hx.reserve(width, height);
+        hx.extractAsync(image_data, width, height, f);
+        before = hx.deviceResult();
+        // CudaMatcher.cpp:35-37: nothing to match against an empty previous frame
+        if (have_prev && n_prev > 0 && hm.residentRows() == n_prev)
+            queued = hm.matchDeviceAsync(before.descriptors, before.count, before.rows, !cfg_.legacy_order, cfg_.ratio_threshold);
+        hx.sync();
+    } else {
+        hx.extract(image_data, width, height, f);
+    }
+    const adapters::hip::OrbHipExtractor::DeviceResult dr = hx.deviceResult();
+    const int n = (int)f.numKeypoints();
+    if (queued) {
+        std::vector<core::Match> got;
+        hm.finishDevice(n, got);
+        // a tie storm made the extractor grow (and move) its result block during sync(): what was queued read a partial
+        // set -- match again from the block as it is now
+        if (dr.descriptors == before.descriptors && n <= before.rows) {
+            result_.matches.insert(result_.matches.end(), got.begin(), got.end());
+            return;
+        }
+        hm.retainDevice(nullptr, 0);
+    }
+    if (have_prev && n > 0 && n_prev > 0 && hm.residentRows() == n_prev) {
+        if (cfg_.legacy_order) hm.matchDevice(nullptr, n_prev, dr.descriptors, n, result_.matches, cfg_.ratio_threshold);
+        else hm.matchDevice(dr.descriptors, n, nullptr, n_prev, result_.matches, cfg_.ratio_threshold);
+    } else if (have_prev && n > 0 && n_prev > 0) {
+        // the resident set is not the previous frame's (another caller used the matcher): ordinary port call
+        if (cfg_.legacy_order) matcher_->match(*cur_, f, result_.matches, cfg_.ratio_threshold);
+        else matcher_->match(f, *cur_, result_.matches, cfg_.ratio_threshold);
+        hm.retainDevice(dr.descriptors, n);
+    } else {
+        hm.reserve(dr.rows, dr.rows);                    // (before anything is resident: growing the handle drops it)
+        hm.retainDevice(dr.descriptors, n);              // first frame, or an empty one: only becomes the resident set
+    }
 }
 
 FrontEnd::FrontEnd(interfaces::FeatureExtractorPtr extractor, interfaces::MatcherPtr matcher,
@@ -36,17 +98,13 @@ const FrontEndResult& FrontEnd::processFrame(const std::uint8_t* image_data, int
     std::unique_ptr<core::Frame> f = std::make_unique<core::Frame>();
     f->id = next_id_++;
     f->timestamp = timestamp;
-    extractor_->extract(image_data, width, height, *f);            // H12_CLEAN_ARCHITECTURE.md:597
+    result_.matches.clear();
+    extractAndMatch(image_data, width, height, *f);
 
     prev_ = std::move(cur_);
     cur_ = std::move(f);
     result_.frame = cur_.get();
     result_.previous = prev_.get();
-    result_.matches.clear();
-    if (prev_) {
-        if (cfg_.legacy_order) matcher_->match(*prev_, *cur_, result_.matches, cfg_.ratio_threshold);   // euroc_eval.cpp:168-169
-        else matcher_->match(*cur_, *prev_, result_.matches, cfg_.ratio_threshold);                      // H12...:601
-    }
     result_.filtered_count = 0;
     if (cfg_.filter_dynamic_objects && prev_ && !detections_.empty()) {        // main.cpp:164-175
         const core::Frame& qf = cfg_.legacy_order ? *prev_ : *cur_;

@@ -6,13 +6,24 @@
 #include "aria_hip/HipLoopDetector.hpp"
 #include "aria_hip/HipMatcher.hpp"
 #include "aria_hip/OrbHipExtractor.hpp"
+#include "aria_orb_hip.h"
 
 namespace aria::factory {
 
 HipComponents createHipComponents(const HipFactoryConfig& cfg) {
     HipComponents c;
-    c.extractor = std::make_unique<adapters::hip::OrbHipExtractor>(cfg.max_features, cfg.stream, cfg.hip_device);
-    c.matcher = std::make_unique<adapters::hip::HipMatcher>(cfg.stream, cfg.hip_device);
+    void* stream = cfg.stream;
+    if (!stream) {
+        // one stream for extractor and matcher: the matcher's work can then be queued behind the extraction
+        // (FrontEndConfig::device_handoff). If the device is not usable the components report that themselves.
+        const int dev = cfg.hip_device;
+        if (aria_stream_create(dev, &stream) == ARIA_OK && stream)
+            c.shared_stream = std::shared_ptr<void>(stream, [dev](void* s) { aria_stream_destroy(dev, s); });
+        else
+            stream = nullptr;
+    }
+    c.extractor = std::make_unique<adapters::hip::OrbHipExtractor>(cfg.max_features, stream, cfg.hip_device);
+    c.matcher = std::make_unique<adapters::hip::HipMatcher>(stream, cfg.hip_device);
     if (cfg.enable_loop_closure)
         // slot rows: nfeatures + 64 rows of tie slack per level (aria_orb_kp_capacity), rounded up
         c.loop_detector = std::make_unique<adapters::hip::HipLoopDetector>(
@@ -23,7 +34,9 @@ HipComponents createHipComponents(const HipFactoryConfig& cfg) {
 
 std::unique_ptr<pipeline::FrontEnd> createHip(const HipFactoryConfig& cfg) {
     HipComponents c = createHipComponents(cfg);
-    return std::make_unique<pipeline::FrontEnd>(std::move(c.extractor), std::move(c.matcher), std::move(c.loop_detector), cfg.frontend);
+    auto fe = std::make_unique<pipeline::FrontEnd>(std::move(c.extractor), std::move(c.matcher), std::move(c.loop_detector), cfg.frontend);
+    fe->setKeepAlive(std::move(c.shared_stream));
+    return fe;
 }
 
 }  // namespace aria::factory

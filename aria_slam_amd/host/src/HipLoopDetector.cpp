@@ -49,6 +49,7 @@ std::vector<std::pair<int, double>> HipLoopDetector::findCandidates(const core::
     std::vector<std::pair<int, double>> candidates;
     if (query.frame.descriptors.empty()) return candidates;                        // LoopClosure.cpp:75
     const int nq = (int)query.frame.numKeypoints();
+    if ((size_t)nq * 32 > query.frame.descriptors.size()) fail("findCandidates: descriptors shorter than numKeypoints()*32", ARIA_E_INVALID);
     matcher_.reserve(nq, slot_rows_);
     int n_kf = 0;
     int rc = aria_kfdb_scan(db_, matcher_.handle(), query.frame.descriptors.data(), nq, 0.7, good_.data(), (int)good_.size(), &n_kf);
@@ -71,25 +72,24 @@ std::vector<std::pair<int, double>> HipLoopDetector::findCandidates(const core::
 std::optional<core::LoopCandidate> HipLoopDetector::detect(const core::KeyFrame& query) {
     if (size() < min_frames_between_) return std::nullopt;                          // :34-36
     const auto candidates = findCandidates(query);                                  // :39
-    std::vector<std::uint8_t> kf_desc;
+    const int nq = (int)query.frame.numKeypoints();
     for (const auto& [idx, score] : candidates) {
         if (score < min_score_) continue;                                           // :42
         long long id = 0;
         int cnt = 0;
         aria_kfdb_info(db_, idx, &id, &cnt);
         if ((long long)query.id - id < (long long)min_frames_between_) continue;    // :47
-        // verification: the ratio-0.7 match list (LoopClosure.cpp:120-131), at least min_matches of them
-        kf_desc.resize((size_t)cnt * 32);
+        // verification: the ratio-0.7 match list (LoopClosure.cpp:120-131), at least min_matches of them. The keyframe is
+        // matched where it lies in the database (no download + upload of its descriptors)
+        match_buf_.resize((size_t)std::max(nq, 1));
         int n = 0;
-        int rc = aria_kfdb_fetch(db_, idx, kf_desc.data(), cnt, &n);
-        if (rc != ARIA_OK) fail("aria_kfdb_fetch", rc);
-        core::Frame kf_frame;
-        kf_frame.keypoints.resize((size_t)n);
-        kf_frame.descriptors = kf_desc;
-        core::LoopCandidate cand;
-        matcher_.match(query.frame, kf_frame, cand.matches, 0.7f);
+        int rc = aria_kfdb_match(db_, matcher_.handle(), idx, query.frame.descriptors.data(), nq, 0.7f,
+                                 reinterpret_cast<aria_match*>(match_buf_.data()), (int)match_buf_.size(), &n);
+        if (rc != ARIA_OK) fail("aria_kfdb_match", rc);
+        core::LoopCandidate cand{};
+        cand.matches.assign(match_buf_.begin(), match_buf_.begin() + n);
         if ((int)cand.matches.size() < min_matches_) continue;
-        if (verifier_ && !verifier_(query, (std::uint64_t)id, cand.matches, cand.relative_pose)) continue;
+        if (verifier_ && !verifier_(query, (std::uint64_t)id, cand)) continue;
         cand.query_id = query.id;                                                   // :57-61
         cand.match_id = (std::uint64_t)id;
         cand.score = score;

@@ -55,6 +55,41 @@ void HipMatcher::match(const core::Frame& query, const core::Frame& train, std::
     matches.insert(matches.end(), buf_.begin(), buf_.begin() + n);            // :65 push_back, never cleared
 }
 
+void HipMatcher::matchDevice(const std::uint8_t* d_query, int nq, const std::uint8_t* d_train, int nt,
+                             std::vector<core::Match>& matches, float ratio_threshold) {
+    ensure(std::max(nq, 1), std::max(nt, 1));
+    buf_.resize((size_t)std::max(nq, 1));
+    int n = 0;
+    int rc = aria_matcher_match_device(m_, d_query, nq, d_train, nt, ratio_threshold, reinterpret_cast<aria_match*>(buf_.data()),
+                                       (int)buf_.size(), &n);
+    if (rc != ARIA_OK) fail("aria_matcher_match_device", rc);
+    matches.insert(matches.end(), buf_.begin(), buf_.begin() + n);
+}
+
+void HipMatcher::retainDevice(const std::uint8_t* d_desc, int n) {
+    ensure(std::max(n, 1), 1);
+    int rc = aria_matcher_retain_device(m_, d_desc, n);
+    if (rc != ARIA_OK) fail("aria_matcher_retain_device", rc);
+}
+
+int HipMatcher::residentRows() const { return m_ ? aria_matcher_resident_rows(m_) : -1; }
+
+bool HipMatcher::matchDeviceAsync(const std::uint8_t* d_new, const int* d_count, int rows_max, bool new_is_query,
+                                  float ratio_threshold) {
+    if (!m_ || rows_max > cap_q_ || rows_max > cap_t_ || aria_matcher_resident_rows(m_) < 1) return false;
+    int rc = aria_matcher_match_device_async(m_, d_new, d_count, rows_max, new_is_query ? 1 : 0, ratio_threshold);
+    if (rc != ARIA_OK) fail("aria_matcher_match_device_async", rc);
+    return true;
+}
+
+void HipMatcher::finishDevice(int n_new, std::vector<core::Match>& matches) {
+    buf_.resize((size_t)std::max(cap_q_, 1));
+    int n = 0;
+    int rc = aria_matcher_finish(m_, n_new, reinterpret_cast<aria_match*>(buf_.data()), (int)buf_.size(), &n);
+    if (rc != ARIA_OK) fail("aria_matcher_finish", rc);
+    matches.insert(matches.end(), buf_.begin(), buf_.begin() + n);
+}
+
 void HipMatcher::matchMultiple(const core::Frame& query, const std::vector<core::Frame>& candidates,
                                std::vector<std::vector<core::Match>>& all_matches, float ratio_threshold) {
     all_matches.resize(candidates.size());                                      // IMatcher.hpp:33
@@ -86,6 +121,7 @@ std::vector<std::pair<int, double>> HipMatcher::findLoopCandidates(const core::F
     std::vector<std::pair<int, double>> candidates;
     if (query.descriptors.empty()) return candidates;                          // LoopClosure.cpp:75
     const int nq = (int)query.numKeypoints();
+    if ((size_t)nq * 32 > query.descriptors.size()) fail("findLoopCandidates: descriptors shorter than numKeypoints()*32", ARIA_E_INVALID);
     // the keyframes that pass the host-side filters (:81, :83) go to the device in one batch: one upload of the query,
     // one kNN-2 launch over all of them (the reference runs one CPU knnMatch per keyframe, :87)
     std::vector<int> which;
@@ -96,6 +132,7 @@ std::vector<std::pair<int, double>> HipMatcher::findLoopCandidates(const core::F
         const core::Frame& kf = keyframes[i];
         if ((long long)query.id - (long long)kf.id < (long long)min_frames_between) continue;   // :81
         if (kf.descriptors.empty()) continue;                                  // :83
+        if (kf.numKeypoints() * 32 > kf.descriptors.size()) fail("findLoopCandidates: descriptors shorter than numKeypoints()*32", ARIA_E_INVALID);
         which.push_back((int)i);
         ptrs.push_back(kf.descriptors.data());
         nts.push_back((int)kf.numKeypoints());

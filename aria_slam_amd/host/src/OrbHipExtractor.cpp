@@ -98,6 +98,16 @@ void OrbHipExtractor::sync() {
     fill(*f, pending_width_, pending_height_, n);
 }
 
+OrbHipExtractor::DeviceResult OrbHipExtractor::deviceResult() const {
+    DeviceResult r;
+    if (!h_) return r;
+    const aria_keypoint* kp = nullptr;
+    int rc = aria_orb_last_device(h_, &kp, &r.descriptors, &r.count, &r.n, &r.rows);
+    if (rc != ARIA_OK) return DeviceResult{};
+    r.keypoints = reinterpret_cast<const core::KeyPoint*>(kp);
+    return r;
+}
+
 void OrbHipExtractor::setMaxFeatures(int n) {                  // OrbCudaExtractor.cpp:212-216
     if (n < 0) fail("setMaxFeatures", ARIA_E_INVALID);
     max_features_ = n;

@@ -235,12 +235,19 @@ def verify_last_step(A, torch, dev, images, last, halo_img, B, W, H, NF, cap, ra
 def single_frame_latency(A, dev, images, W, H, NF, n=48):
     """What a frame-at-a-time caller of IFeatureExtractor::extract / IMatcher::match sees (one frame in flight, pageable host
     buffers in and out, PCIe both ways, sync per call): the host entry points replay a hipGraph of a latency schedule.
+    Three figures: extract alone; extract + match with the descriptors handed over on the device (getGpuDescriptors /
+    matchGpu, what aria::pipeline::FrontEnd does with the HIP adapters: the match is queued behind extractAsync on a shared
+    stream, one wait per frame); extract + match through host buffers only (the plain port calls).
     Never `value`: reported beside it."""
     import ctypes as C
+    import torch
     n = min(n, images.shape[0])
     seq = images[:n].cpu().numpy()
+    stream = torch.cuda.Stream(device=dev)
     e = A.OrbHipExtractor(max_features=NF, device=dev.index, max_width=W, max_height=H)
     m = A.HipMatcher(device=dev.index)
+    e2 = A.OrbHipExtractor(max_features=NF, device=dev.index, max_width=W, max_height=H, stream=stream.cuda_stream)
+    m2 = A.HipMatcher(device=dev.index, stream=stream.cuda_stream)
     try:
         L = e._L
         cap = e.kp_capacity()
@@ -250,8 +257,8 @@ def single_frame_latency(A, dev, images, W, H, NF, n=48):
         cnt = [C.c_int(), C.c_int()]
         nm = C.c_int()
 
-        def ext(i, slot):
-            rc = L.aria_orb_extract(e._h, seq[i].ctypes.data, W, H, W, kp[slot].ctypes.data, ds[slot].ctypes.data, cap, C.byref(cnt[slot]))
+        def ext(i, slot, h=None):
+            rc = L.aria_orb_extract((h or e)._h, seq[i].ctypes.data, W, H, W, kp[slot].ctypes.data, ds[slot].ctypes.data, cap, C.byref(cnt[slot]))
             assert rc == 0, rc
         for i in range(min(8, n)):
             ext(i, 0)
@@ -270,13 +277,41 @@ def single_frame_latency(A, dev, images, W, H, NF, n=48):
                                           C.c_float(0.75), mt.ctypes.data, cap, C.byref(nm))
                 assert rc == 0, rc
         t2 = time.perf_counter()
-        return {"what": "aria_orb_extract / + aria_matcher_match through host buffers, one frame in flight, sync per call "
-                        "(hipGraph replay of the single-frame latency schedule); PCIe-inclusive, never `value`",
+        host_matches = mt[:nm.value].copy()
+        # device hand-off: extractAsync, the match queued behind it on the same stream, ONE wait, then the results
+        ext(0, 1, e2)
+        _, d_desc, d_cnt, n0, rows = e2.device_result()
+        m2.retain_device(d_desc, n0)
+        dev_matches = None
+        for rep in range(reps + 1):
+            if rep == 1:
+                t3 = time.perf_counter()
+            for i in range(n):
+                s = i & 1
+                rc = L.aria_orb_extract_async(e2._h, seq[i].ctypes.data, W, H, W)
+                assert rc == 0, rc
+                rc = L.aria_matcher_match_device_async(m2._h, d_desc, d_cnt, rows, 1, C.c_float(0.75))
+                assert rc == 0, rc
+                rc = L.aria_orb_sync(e2._h, kp[s].ctypes.data, ds[s].ctypes.data, cap, C.byref(cnt[s]))
+                assert rc == 0, rc
+                rc = L.aria_matcher_finish(m2._h, cnt[s].value, mt.ctypes.data, cap, C.byref(nm))
+                assert rc == 0, rc
+        t4 = time.perf_counter()
+        dev_matches = mt[:nm.value].copy()
+        assert dev_matches.tobytes() == host_matches.tobytes(), "device hand-off and host-buffer matches differ"
+        return {"what": "aria_orb_extract(+ match), one frame in flight, pageable host buffers, PCIe-inclusive, never `value`. "
+                        "extract_plus_match_us: descriptors handed over on the device (aria_orb_last_device + "
+                        "aria_matcher_match_device_async queued behind aria_orb_extract_async on one stream, one wait per "
+                        "frame) = what aria::pipeline::FrontEnd runs; extract_plus_match_host_buffers_us: the two port "
+                        "calls through host buffers, a wait each",
                 "extract_us": round(1e6 * (t1 - t0) / (reps * n), 1),
-                "extract_plus_match_us": round(1e6 * (t2 - t1) / (reps * n), 1), "frames": reps * n}
+                "extract_plus_match_us": round(1e6 * (t4 - t3) / (reps * n), 1),
+                "extract_plus_match_host_buffers_us": round(1e6 * (t2 - t1) / (reps * n), 1), "frames": reps * n}
     finally:
         e.close()
         m.close()
+        e2.close()
+        m2.close()
 
 
 def loop_closure_leg(A, torch, dist, dev, mat, last, B, cap, rank, world, rehearsal, lo_frame):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ARIA_ORB_HIP_ABI_VERSION 2
+#define ARIA_ORB_HIP_ABI_VERSION 3
 
 typedef enum {
     ARIA_OK = 0,
@@ -116,6 +116,17 @@ int aria_orb_extract(aria_orb_t h, const uint8_t* image, int width, int height, 
 int aria_orb_extract_async(aria_orb_t h, const uint8_t* image, int width, int height, int stride);
 int aria_orb_sync(aria_orb_t h, aria_keypoint* keypoints, uint8_t* descriptors, int cap, int* n_out);
 
+/* OrbCudaExtractor::getGpuDescriptors() (include/adapters/gpu/OrbCudaExtractor.hpp:34-35, "get descriptors without
+ * download (for GPU matching)"): device pointers to the result of the single-frame entry points, for a matcher on the same
+ * device (aria_matcher_match_device*). The block belongs to the handle: the pointers stay the same from call to call
+ * (until a tie storm makes the handle grow it, or aria_orb_set_max_features) and the CONTENT is that of the most recent
+ * aria_orb_extract / aria_orb_extract_async, complete once that call / aria_orb_sync has returned -- or, for work queued
+ * behind it on the handle's stream, as soon as the extraction's kernels have run. *d_count is the device copy of the
+ * keypoint count (clamped to *rows = the block's row capacity), *n the host copy (-1 while an async extract is pending,
+ * or before the first extraction). Any output pointer may be NULL. */
+int aria_orb_last_device(aria_orb_t h, const aria_keypoint** d_keypoints, const uint8_t** d_descriptors, const int** d_count,
+                         int* n, int* rows);
+
 /* Device-resident batch form: the role OrbCudaExtractor::getGpuDescriptors() was meant to play
  * (include/adapters/gpu/OrbCudaExtractor.hpp:35) -- results stay in HBM for the matcher.
  *   d_images     : n_frames images, frame f at d_images + f*frame_stride, rows row_stride bytes apart
@@ -195,6 +206,30 @@ void aria_matcher_destroy(aria_matcher_t m);
 int aria_matcher_match(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* train_desc, int nt,
                float ratio, aria_match* matches, int cap, int* n_out);
 
+/* CudaMatcher::matchGpu (include/adapters/gpu/CudaMatcher.hpp:22-28, "GPU-to-GPU matching, zero-copy when used with
+ * OrbCudaExtractor"): the descriptor sets are device pointers (e.g. aria_orb_last_device), the matches come back to the
+ * host; same results as aria_matcher_match on the same rows. The handle keeps ONE descriptor set resident between calls
+ * (device copy): a NULL d_query or d_train stands for that resident set, whose row count must then equal nq / nt. After
+ * the call the resident set is the one passed as a non-NULL pointer (the query when both are given) -- frame i against
+ * frame i-1 is match_device(d_cur, n_cur, NULL, n_prev) in SlamPipeline's order (query = current) or
+ * match_device(NULL, n_prev, d_cur, n_cur) in the legacy executables' order (query = previous, src/euroc_eval.cpp:168-169).
+ * aria_matcher_retain_device makes a set resident without matching (first frame); aria_matcher_resident_rows tells its
+ * rows (-1: none). aria_matcher_match (host buffers) also replaces the resident set, by its query. */
+int aria_matcher_match_device(aria_matcher_t m, const uint8_t* d_query, int nq, const uint8_t* d_train, int nt, float ratio,
+                              aria_match* matches, int cap, int* n_out);
+int aria_matcher_retain_device(aria_matcher_t m, const uint8_t* d_desc, int n);
+int aria_matcher_resident_rows(aria_matcher_t m);
+/* Pipelined form for a caller whose extractor and matcher share one stream (extractAsync ... sync, the shape of
+ * SlamPipeline's async variant, docs/milestones/H12_CLEAN_ARCHITECTURE.md:711-716): the match of the NEW set (d_new, row count
+ * read on the device from *d_n_new <= n_new_max, e.g. aria_orb_last_device's d_count) against the resident set is queued
+ * on the matcher's stream without waiting -- behind the extraction when both handles were given the same stream -- and
+ * aria_matcher_finish synchronises, is told the new set's row count (which the caller knows by then) and returns the
+ * matches. new_is_query: 1 = query is the new set, 0 = query is the resident set. One pending operation per handle
+ * (ARIA_E_BUSY); aria_matcher_finish without one returns ARIA_E_NOT_PENDING. */
+int aria_matcher_match_device_async(aria_matcher_t m, const uint8_t* d_new, const int* d_n_new, int n_new_max, int new_is_query,
+                                    float ratio);
+int aria_matcher_finish(aria_matcher_t m, int n_new, aria_match* matches, int cap, int* n_out);
+
 /* Raw kNN-2 (cv::BFMatcher::knnMatch(k=2) itself), host buffers: idx/dist hold 2 ints per query
  * (nearest, second nearest); idx = -1 / dist = INT_MAX where the train set is too small. */
 int aria_matcher_knn2(aria_matcher_t m, const uint8_t* query_desc, int nq, const uint8_t* train_desc, int nt,
@@ -256,6 +291,10 @@ int  aria_kfdb_add(aria_kfdb_t db, long long id, const uint8_t* desc_host, int n
 int  aria_kfdb_add_device(aria_kfdb_t db, long long id, const uint8_t* d_desc, int n);
 int  aria_kfdb_info(aria_kfdb_t db, int index, long long* id, int* count);
 int  aria_kfdb_fetch(aria_kfdb_t db, int index, uint8_t* desc_host, int cap_rows, int* n_out);
+/* The ratio-test match list of the query against keyframe `index` (LoopClosure.cpp:120-131, the list verifyGeometry starts
+ * from), matched where the keyframe lies in HBM; same result as aria_matcher_match(query, fetched keyframe). Host query. */
+int  aria_kfdb_match(aria_kfdb_t db, aria_matcher_t m, int index, const uint8_t* query_desc, int nq, float ratio,
+                     aria_match* matches, int cap, int* n_out);
 /* good[i] for every keyframe i (ratio test in double, LoopClosure.cpp:92); *n_out = keyframes. Host query. */
 int  aria_kfdb_scan(aria_kfdb_t db, aria_matcher_t m, const uint8_t* query_desc, int nq, double ratio, int* good, int cap,
                     int* n_out);
@@ -267,6 +306,12 @@ int aria_matcher_get_profile(aria_matcher_t m, int reset, double* stage_ms /*[2]
                              int64_t* pairs);
 void* aria_matcher_stream(aria_matcher_t m);
 int   aria_matcher_sync(aria_matcher_t m);
+
+/* cudaStreamCreate / cudaStreamDestroy as the reference adapters use them (OrbCudaExtractor.cpp:28,50; CudaMatcher.cpp:16,24)
+ * for hosts that do not link the HIP runtime: a stream to pass as aria_orb_config.stream AND aria_matcher_config.stream,
+ * which orders the two handles' work (needed by aria_matcher_match_device_async). Destroy it after the handles. */
+int aria_stream_create(int device, void** stream);
+int aria_stream_destroy(int device, void* stream);
 
 /* ---- synthetic workload: integer-only generator, identical bytes everywhere ------------ */
 int aria_synth_frame_pair(uint64_t seed, int width, int height, uint8_t* frame_a, uint8_t* frame_b);

@@ -187,6 +187,50 @@ int main(int argc, char** argv) {
         std::printf("factory %zu %zu %zu %d %d\n", n0, r1.frame->numKeypoints(), r1.matches.size(), (int)r1.is_keyframe,
                     fe->loopDetector() != nullptr);
     }
+    // getGpuDescriptors() / matchGpu hand-off (OrbCudaExtractor.hpp:34-35, CudaMatcher.hpp:22-28): same matches as the host
+    // port calls, in both query/train orders, with the previous frame's set resident in the matcher
+    {
+        adapters::hip::OrbHipExtractor ex(2000);
+        adapters::hip::HipMatcher mt;
+        core::Frame ga, gb;
+        ex.extract(a.data(), W, H, ga);
+        auto da = ex.deviceResult();
+        mt.retainDevice(da.descriptors, (int)ga.numKeypoints());
+        ex.extract(b.data(), W, H, gb);
+        auto db = ex.deviceResult();
+        std::vector<core::Match> m_cur_prev, m_prev_cur, m_both;
+        mt.matchDevice(db.descriptors, (int)gb.numKeypoints(), nullptr, (int)ga.numKeypoints(), m_cur_prev);     // b vs resident a
+        std::printf("dev_n %d %d rows %d resident %d\n", da.n, db.n, db.rows, mt.residentRows());
+        // resident is b now; legacy order for the next frame (a again): query = previous (b), train = current (a)
+        ex.extract(a.data(), W, H, ga);
+        auto da2 = ex.deviceResult();
+        mt.matchDevice(nullptr, (int)gb.numKeypoints(), da2.descriptors, (int)ga.numKeypoints(), m_prev_cur);     // resident b vs a
+        mt.matchDevice(da2.descriptors, (int)ga.numKeypoints(), da2.descriptors, (int)ga.numKeypoints(), m_both); // a vs a, both explicit
+        std::printf("dev_match %016llx %016llx %016llx\n", fnv(m_cur_prev.data(), m_cur_prev.size() * sizeof(core::Match)),
+                    fnv(m_prev_cur.data(), m_prev_cur.size() * sizeof(core::Match)), fnv(m_both.data(), m_both.size() * sizeof(core::Match)));
+        std::printf("dev_ptr_stable %d\n", (int)(da.descriptors == db.descriptors && db.descriptors == da2.descriptors && da.descriptors != nullptr));
+    }
+    // FrontEnd over the same four frames in its three hand-off modes and both orders: identical matches
+    for (int legacy = 0; legacy < 2; legacy++) {
+        for (int mode = 0; mode < 3; mode++) {
+            factory::HipFactoryConfig fc;
+            fc.max_features = 2000;
+            fc.enable_loop_closure = false;
+            fc.frontend.legacy_order = legacy != 0;
+            fc.frontend.device_handoff = mode != 0;
+            std::unique_ptr<pipeline::FrontEnd> fe;
+            if (mode == 2) fe = factory::createHip(fc);                 // one stream for both components
+            else fe = std::make_unique<pipeline::FrontEnd>(std::make_unique<adapters::hip::OrbHipExtractor>(2000),
+                                                           std::make_unique<adapters::hip::HipMatcher>(), fc.frontend);
+            std::printf("fe_%d_%d mode %d", legacy, mode, fe->handoffMode());
+            const uint8_t* seq[4] = {a.data(), b.data(), a.data(), b.data()};
+            for (int i = 0; i < 4; i++) {
+                const auto& r = fe->processFrame(seq[i], W, H, 0.05 * i);
+                std::printf(" %zu:%016llx", r.matches.size(), fnv(r.matches.data(), r.matches.size() * sizeof(core::Match)));
+            }
+            std::printf("\n");
+        }
+    }
     std::printf("DONE\n");
     return 0;
 }

@@ -74,5 +74,27 @@ def test_adapters_equal_python_binding_and_reference_conventions(aria, selftest)
     assert kv["ld_loop"][0] == "1" and kv["ld_loop"][1] == "1" and int(kv["ld_loop"][2]) == len(m.match(fb, fb, None, 0.7)) and kv["ld_loop"][3] == "1"
     assert kv["ld_recent"] == ["0"]
     assert kv["factory"] == [str(len(fa["keypoints"])), str(len(fb["keypoints"])), str(len(mm)), "1", "1"]
+    # device hand-off (getGpuDescriptors / matchGpu): equal to the host port calls, which the parity tests pin to the oracle
+    from oracle import oracle_py as O2
+    e.setMaxFeatures(2000)
+    fa2, fb2 = e.extract(a), e.extract(b)
+    want_ba = O2.match_ratio(fb2["descriptors"], fa2["descriptors"], 0.75)
+    want_ab = O2.match_ratio(fa2["descriptors"], fb2["descriptors"], 0.75)
+    want_aa = O2.match_ratio(fa2["descriptors"], fa2["descriptors"], 0.75)
+    assert kv["dev_n"][:2] == [str(len(fa2["keypoints"])), str(len(fb2["keypoints"]))] and kv["dev_n"][5] == str(len(fb2["keypoints"]))
+    # resident b as the query against a: the legacy order of the next frame (euroc_eval.cpp:168-169)
+    want_b_a = O2.match_ratio(fb2["descriptors"], fa2["descriptors"], 0.75)
+    assert kv["dev_match"] == [_fnv(want_ba.tobytes()), _fnv(want_b_a.tobytes()), _fnv(want_aa.tobytes())]
+    assert kv["dev_ptr_stable"] == ["1"]
+    for legacy in (0, 1):
+        rows = [kv["fe_%d_%d" % (legacy, mode)] for mode in range(3)]
+        assert [r[1] for r in rows] == ["0", "1", "2"]                     # host calls, device hand-off, queued behind extractAsync
+        assert rows[0][2:] == rows[1][2:] == rows[2][2:], rows
+        pairs = [(fb2, fa2), (fa2, fb2), (fb2, fa2)]                       # (current, previous) of frames 1..3
+        exp = ["0:%s" % _fnv(b"")]
+        for cur, prev in pairs:
+            w = O2.match_ratio(prev["descriptors"], cur["descriptors"], 0.75) if legacy else O2.match_ratio(cur["descriptors"], prev["descriptors"], 0.75)
+            exp.append("%d:%s" % (len(w), _fnv(w.tobytes())))
+        assert rows[0][2:] == exp
     e.close()
     m.close()

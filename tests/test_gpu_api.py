@@ -788,3 +788,162 @@ def test_stage_event_is_recorded_before_select(aria, torch_cuda):
         torch.cuda.synchronize(dev)
     finally:
         e.close()
+
+
+# ---- round 3: advisor findings and the device-resident single-frame hand-off ---------------------------------
+def test_match_graph_survives_key_buffer_growth(aria, oracle):
+    """the captured single-pair graphs have the key buffer's address baked in. A call that makes the
+    handle grow that buffer (matchMultiple with more candidates than the initial 16 slices' worth) must drop them: the
+    same pair matched before and after has to give the oracle's matches, not a replay against freed memory."""
+    a, b = aria.synth_frame_pair(21)
+    e = _ext(aria, nf=1500)
+    m = aria.HipMatcher()
+    try:
+        fa, fb = e.extract(a), e.extract(b)
+        want = oracle.match_ratio(fb["descriptors"], fa["descriptors"], 0.75)
+        for _ in range(3):                                    # third call replays the captured graph
+            assert m.match(fb, fa).tobytes() == want.tobytes()
+        L = m._L
+        L.aria_matcher_match_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                               C.c_void_p, C.c_int, C.c_void_p]
+        ncand = 20                                            # > kKnnSplitMax = 16 -> the key buffer is reallocated
+        q = np.ascontiguousarray(fb["descriptors"])
+        cands = [np.ascontiguousarray(fa["descriptors"] if i % 2 == 0 else fb["descriptors"]) for i in range(ncand)]
+        ptrs = (C.c_void_p * ncand)(*[c.ctypes.data for c in cands])
+        nts = (C.c_int * ncand)(*[len(c) for c in cands])
+        out = np.empty((ncand, len(q)), aria.MATCH_DTYPE)
+        n_out = (C.c_int * ncand)()
+        rc = L.aria_matcher_match_multi(m._h, q.ctypes.data, len(q), ptrs, nts, ncand, C.c_float(0.75), out.ctypes.data, len(q), n_out)
+        assert rc == 0
+        for i in range(ncand):
+            w = want if i % 2 == 0 else oracle.match_ratio(q, q, 0.75)
+            assert out[i, :n_out[i]].tobytes() == w.tobytes()
+        for _ in range(4):                                    # eager, eager, capture, replay -- all against the new buffer
+            assert m.match(fb, fa).tobytes() == want.tobytes()
+            assert m.match(fa, fb).tobytes() == oracle.match_ratio(fa["descriptors"], fb["descriptors"], 0.75).tobytes()
+    finally:
+        e.close()
+        m.close()
+
+
+def test_batch_error_survives_a_single_frame_call(aria, torch_cuda):
+    """a single-frame extraction between a batch call and aria_orb_check must not wipe the batch's deferred
+    error words (they used to share the single-frame result header)."""
+    torch = torch_cuda
+    seq = aria.synth_sequence(1, 1, 640, 480)
+    dev = torch.device("cuda", 0)
+    images = torch.from_numpy(seq).to(dev)
+    e = aria.OrbHipExtractor(max_features=2000, max_width=640, max_height=480, max_batch=2)
+    try:
+        cap = 100
+        kps = torch.zeros((2, cap, 24), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+        counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.extract_batch_device(images, 2, 640, 480, kps, desc, counts, cap)
+        f = e.extract(seq[0])                                 # zeroes ITS header, not the batch's words
+        assert len(f["keypoints"]) >= 2000
+        with pytest.raises(aria.AriaError) as ex:
+            e.check()
+        assert ex.value.status == -5 and e.rows_needed() >= 2000
+        e.check()
+    finally:
+        e.close()
+
+
+def test_device_handoff_equals_oracle(aria, oracle, torch_cuda):
+    """getGpuDescriptors() / matchGpu (OrbCudaExtractor.hpp:34-35, CudaMatcher.hpp:22-28): the single-frame result is
+    matched where it lies on the device; both orders, the resident-set rule, the explicit form, and the form queued behind
+    extractAsync on a shared stream all give the oracle's matches for the frames' descriptors."""
+    torch = torch_cuda
+    W, H, NF = 640, 480, 2000
+    seq = aria.synth_sequence(31, 3, W, H)                    # 6 frames
+    want_f = [oracle.orb_extract(im, oracle.default_params(NF)) for im in seq]
+    s = torch.cuda.Stream(device=torch.device("cuda", 0))
+    for shared in (False, True):
+        e = aria.OrbHipExtractor(max_features=NF, max_width=W, max_height=H, stream=s.cuda_stream if shared else None)
+        m = aria.HipMatcher(stream=s.cuda_stream if shared else None)
+        try:
+            assert m.resident_rows() == -1
+            prev = None
+            for i, im in enumerate(seq):
+                if shared and prev is not None:
+                    # queued behind the extraction: the matcher reads the keypoint count on the device
+                    fr = e.extractAsync(im)
+                    kp, ds, cnt, n_host, rows = e.device_result()
+                    assert n_host == -1 and rows >= e.kp_capacity()
+                    m.match_device_async(ds, cnt, rows, new_is_query=(i % 2 == 0))
+                    with pytest.raises(aria.AriaError) as ex:                 # one pending operation
+                        m.match_device_async(ds, cnt, rows)
+                    assert ex.value.status == -7
+                    fr = e.sync()
+                    n = len(fr["keypoints"])
+                    got = m.finish(n, max(n, len(prev["keypoints"])))
+                else:
+                    fr = e.extract(im)
+                    kp, ds, cnt, n_host, rows = e.device_result()
+                    n = len(fr["keypoints"])
+                    assert n_host == n
+                    if prev is None:
+                        m.retain_device(ds, n)
+                        got = None
+                    elif i % 2 == 0:
+                        got = m.match_device(ds, n, None, len(prev["keypoints"]))          # query = current
+                    else:
+                        got = m.match_device(None, len(prev["keypoints"]), ds, n)          # query = previous (legacy order)
+                assert fr["keypoints"].tobytes() == want_f[i][0].tobytes()
+                assert np.array_equal(fr["descriptors"], want_f[i][1])
+                if prev is not None:
+                    q, t = (fr, prev) if i % 2 == 0 else (prev, fr)
+                    want = oracle.match_ratio(q["descriptors"], t["descriptors"], 0.75)
+                    assert len(want) > 50 and got.tobytes() == want.tobytes(), (shared, i)
+                assert m.resident_rows() == n
+                prev = fr
+            # explicit form: both sets given; the query becomes the resident one
+            kp, ds, cnt, n_host, rows = e.device_result()
+            d_other = torch.from_numpy(np.ascontiguousarray(want_f[0][1])).cuda()
+            got = m.match_device(ds, n_host, d_other.data_ptr(), len(want_f[0][1]), 0.7)
+            assert got.tobytes() == oracle.match_ratio(want_f[-1][1], want_f[0][1], 0.7).tobytes()
+            # a resident-set size that does not match is refused, and the host entry point still works afterwards
+            with pytest.raises(aria.AriaError) as ex:
+                m.match_device(ds, n_host, None, n_host + 1)
+            assert ex.value.status == -1
+            assert m.match(want_f[1][1], want_f[0][1]).tobytes() == oracle.match_ratio(want_f[1][1], want_f[0][1], 0.75).tobytes()
+            # ... and the host entry point's query is the resident set for a following device call
+            got = m.match_device(None, len(want_f[1][1]), d_other.data_ptr(), len(want_f[0][1]))
+            assert got.tobytes() == oracle.match_ratio(want_f[1][1], want_f[0][1], 0.75).tobytes()
+            n_out = C.c_int()
+            assert m._L.aria_matcher_finish(m._h, 0, None, 0, C.byref(n_out)) == -8      # nothing pending
+        finally:
+            e.close()
+            m.close()
+
+
+def test_kfdb_match_in_place_equals_fetch_then_match(aria, oracle):
+    a, b = aria.synth_frame_pair(5)
+    e = _ext(aria, nf=1000)
+    m = aria.HipMatcher()
+    L = m._L
+    try:
+        fa, fb = e.extract(a), e.extract(b)
+        db = C.c_void_p()
+        L.aria_kfdb_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.aria_kfdb_add.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_int]
+        L.aria_kfdb_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_int)]
+        L.aria_kfdb_destroy.argtypes = [C.c_void_p]
+        assert L.aria_kfdb_create(0, None, 2, 2048, C.byref(db)) == 0
+        for i, f in enumerate((fa, fb, fa)):                  # the third insertion drops the oldest: [fb, fa]
+            d = np.ascontiguousarray(f["descriptors"])
+            assert L.aria_kfdb_add(db, i, d.ctypes.data, len(d)) == 0
+        q = np.ascontiguousarray(fb["descriptors"])
+        out = np.empty(len(q), aria.MATCH_DTYPE)
+        n = C.c_int()
+        for index, kf in ((0, fb), (1, fa)):
+            assert L.aria_kfdb_match(db, m._h, index, q.ctypes.data, len(q), C.c_float(0.7), out.ctypes.data, len(out), C.byref(n)) == 0
+            assert out[:n.value].tobytes() == oracle.match_ratio(q, kf["descriptors"], 0.7).tobytes()
+        assert L.aria_kfdb_match(db, m._h, 2, q.ctypes.data, len(q), C.c_float(0.7), out.ctypes.data, len(out), C.byref(n)) == -1
+        L.aria_kfdb_destroy(db)
+    finally:
+        e.close()
+        m.close()
