@@ -1,0 +1,677 @@
+// k_fast_blur_stream: FAST-9/16 + NMS + 7x7 Gaussian + the bilinear step to the next pyramid level for the batch path,
+// as a STREAMING kernel: one wave walks a 256-pixel-wide column panel of one pyramid level from the first row to the last.
+// SURVEY.md rows a6.1 (pyramid), a6.2 (FAST), a6.3 (border filter), a6.7 (blur). Same bits as k_fast_blur_band.
+//
+// Why this shape (MI355X), and what it removes from k_fast_blur_band (fast_blur_band.hip, still the kernel of the
+// single-frame latency schedule):
+//  * a band workgroup staged 21 rows to produce 13 (1.6x halo recompute of the row pass and the FAST reject) and ran a
+//    chain of dependent phases separated by workgroup barriers (stage -> walk -> score -> map -> NMS -> out) at 2-3
+//    workgroups per CU: the VALU sat idle a quarter of the time. Here a wave owns its panel for the whole height, every
+//    row is loaded once (one dword per lane, requested a group of seven rows ahead), passes through the 7-row register
+//    window once, and there is NO workgroup barrier at all: the waves of a workgroup share nothing but the LDS allocation.
+//  * lanes are not tied to a frame: the rows of all frames of the launch are laid side by side as one virtual row
+//    [halo | w/4 dwords | halo] x frames, and wave k takes virtual dwords 62 k - 1 .. 62 k + 62 (one dword of overlap on
+//    each side provides the neighbours' pixels). A 179-px level fills its waves as well as a 1408-px one: 93-96 % of the
+//    lanes carry pixels at every level (band kernel: 73 % on average, 52 % at the 257-px level).
+//  * the wave keeps the last 16 raw rows of its panel in a private LDS ring (4 KB): neighbour dwords of a new row,
+//    the 16-pixel rings of FAST survivors and the source pixels of the pyramid step are read from there. FAST survivors
+//    (4-point compass reject on every pixel, as before) are queued in LDS and scored densely once per group of seven
+//    rows; corner scores go to a 16-row score ring for the 3x3 non-maximum suppression, which visits corners only.
+//  * REFLECT_101 needs no edge code: a halo lane, and the lane of a partial last dword, load ONE (unaligned) dword from
+//    inside the row and a per-lane v_perm selector puts the mirrored bytes in place; everybody else's selector is the
+//    identity.
+//  * blur_tie_mode (OpenCV's SIMD column filter rounds ties to even, its scalar tail rounds them up) is a per-pixel
+//    flag of the lane, applied in the walk (tail pixels: floor(acc + 0.5) by v_fract + v_fma before the same
+//    v_cvt_pk_u8_f32); waves without a tail pixel take the plain instruction stream.
+// Integer/byte work only: no MFMA. HBM traffic is the algorithmic minimum by construction: every level byte is read
+// once, the blurred level and the next raw level are written once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+#include "orb_device.h"
+#include "orb_kernels.h"
+
+namespace aria {
+
+namespace {
+
+constexpr int kRing = 16;                         // rows of the raw ring and of the score ring (power of two)
+constexpr int kQ1 = 256;                          // survivor queue entries (appended in rounds of at most this many)
+constexpr int kQ2 = 512;                          // corner list entries (beyond: dense scan of the score ring)
+constexpr int kHdrBytes = 64;                     // in front of the raw ring: lane 0's left-neighbour read lands here
+constexpr int kRawBytes = kRing * 256;
+constexpr int kMapBytes = kRing * 256;
+constexpr int kOut = 128;                         // candidate out-list entries (record + frame), flushed 64 at a time
+constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + 64 + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 12.3 KB per wave
+constexpr int kOwned = 62;                        // productive lanes per wave (lanes 1..62)
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b));
+}
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) + __builtin_bit_cast(short2v, b));
+}
+
+// inclusive prefix sum over the 64 lanes of the wave (DPP: Hillis-Steele inside the 16-lane rows, then the row carries)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);     // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Lanes of a wave hand data to each other through LDS without a workgroup barrier: the hardware executes a wave's LDS
+// instructions in order, this keeps the COMPILER from moving a lane's reads above another lane's writes.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// byte offset of level row y inside a ring of kRing rows of 256 bytes (row -3 is slot 0)
+__device__ __forceinline__ int ring_off(int y) { return ((y + 3) & (kRing - 1)) << 8; }
+
+// fast_score.cpp cornerScore<16> for local pixel px of row `row` of the wave's raw ring: max over the 16 nine-arcs of
+// min(v - ring) and of min(ring - v), minus 1; both polarities ride in one register as packed int16. The pixel is a
+// FAST-9 corner for threshold t iff the result is >= t. (k_fast_blur_band's fast_score_pk on ring addresses.)
+__device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int row) {
+    const uint8_t* rm3 = ring + ring_off(row - 3) + px; const uint8_t* rm2 = ring + ring_off(row - 2) + px;
+    const uint8_t* rm1 = ring + ring_off(row - 1) + px; const uint8_t* c = ring + ring_off(row) + px;
+    const uint8_t* rp1 = ring + ring_off(row + 1) + px; const uint8_t* rp2 = ring + ring_off(row + 2) + px;
+    const uint8_t* rp3 = ring + ring_off(row + 3) + px;
+    const uint32_t v = c[0];
+    const uint32_t vhi = v << 16;
+    uint32_t rg[16] = {rp3[0], rp3[1], rp2[2], rp1[3], c[3], rm1[3], rm2[2], rm3[1],
+                       rm3[0], rm3[-1], rm2[-2], rm1[-3], c[-3], rp1[-3], rp2[-2], rp3[-1]};
+    uint32_t Pk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) Pk[k] = pk_sub_i16(v | (rg[k] << 16), rg[k] | vhi);
+    uint32_t M2[16], M4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M2[k] = pk_min_i16(Pk[k], Pk[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) M4[k] = pk_min_i16(M2[k], M2[(k + 2) & 15]);
+    uint32_t Q = 0x80008000u;   // (-32768, -32768)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t m9 = pk_min_i16(pk_min_i16(M4[k], M4[(k + 4) & 15]), Pk[(k + 8) & 15]);
+        Q = pk_max_i16(Q, m9);
+    }
+    const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
+    return max(q0, q1) - 1;
+}
+
+// What a lane is, fixed for the life of the wave.
+struct LaneRole {
+    int frame;            // frame of the launch this lane's dword belongs to
+    int gdw;              // dword index inside the level row (-1: left halo, D: right halo)
+    uint32_t sel;         // v_perm selector that turns the loaded dword into the lane's pixels (identity / mirrored forms)
+    uint32_t xm0, xm1;    // FAST x-range masks of px 0,1 / 2,3 (bit 15, bit 31), zero where the lane must not report
+    uint32_t tailbits;    // bit i: pixel i rounds ties UP (scalar tail of OpenCV's column filter)
+    bool owner;           // stores blurred pixels and reports candidates
+};
+
+}  // namespace
+
+template <int WPB, bool TAIL>
+__device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
+                                            uint8_t* __restrict__ blur, uint32_t* __restrict__ cand, int* __restrict__ cand_cnt,
+                                            int* __restrict__ err, const int l, const int n_frames,
+                                            const uint32_t* __restrict__ tab, uint8_t* __restrict__ raw_next,
+                                            uint8_t* __restrict__ wl, const int wave_id, const int lane, const LaneRole R,
+                                            const int frame0, unsigned long long* __restrict__ stamps) {
+    // diagnostic (ARIA_STREAM_STAMPS=1): s_memtime ticks per phase, summed over the waves of the launch
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PHASE(k) do { if (stamps) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tlast; tlast = tn; } } while (0)
+    const LevelGeom g = P.lv[l];
+    const int w = g.w, h = g.h;
+    uint32_t* s_raw = reinterpret_cast<uint32_t*>(wl + kHdrBytes);                 // [kRing][64] dwords
+    uint8_t* s_rawb = wl + kHdrBytes;
+    uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
+    uint32_t* s_mapw = reinterpret_cast<uint32_t*>(s_map);
+    uint32_t* s_q1 = reinterpret_cast<uint32_t*>(wl + kHdrBytes + kRawBytes + kMapBytes + 64);
+    uint32_t* s_q2 = s_q1 + kQ1;
+    uint32_t* s_out = s_q2 + kQ2;              // [kOut] candidate records, [kOut] their frames
+    uint32_t* s_outf = s_out + kOut;
+
+    // ---- addresses: wave-uniform 64-bit bases + 32-bit lane offsets ----
+    int pitch_in;
+    const uint8_t* src0 = raw_level_ptr(P, S, raw, frame0, l, pitch_in);           // level l of frame0
+    const int64_t fstride_in = l == 0 ? S.frame_stride : P.raw_frame_bytes;
+    const int r4 = w & 3, D = (w + 3) >> 2;
+    int xload;
+    if (R.gdw < 0) xload = 1;
+    else if (R.gdw >= D) xload = r4 ? w - 9 + r4 : w - 5;
+    else if (r4 && R.gdw == D - 1) xload = w - 4;
+    else xload = 4 * R.gdw;
+    const uint32_t in_off = (uint32_t)((int64_t)(R.frame - frame0) * fstride_in + xload);
+    uint8_t* blur0 = blur + (int64_t)frame0 * P.blur_frame_bytes + g.blur_off;
+    const uint32_t out_off = (uint32_t)((int64_t)(R.frame - frame0) * P.blur_frame_bytes + 4 * max(R.gdw, 0));
+
+    // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); FAST is needed on that region + 1 ring
+    const int fy0 = kEdgeThreshold - 1, fy1 = h - kEdgeThreshold;
+    const int thr = P.fast_threshold;
+    const uint32_t T2 = (uint32_t)thr * 0x00010001u;
+    const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
+    const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
+
+    // per-pixel rounding flags of the column pass (TAIL variant): bias 0.5 and "take the floor" for tail pixels
+    float tb[4] = {0.f, 0.f, 0.f, 0.f}, tm[4] = {0.f, 0.f, 0.f, 0.f};
+    if (TAIL) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { tb[j] = (R.tailbits >> j) & 1u ? 0.5f : 0.f; tm[j] = (R.tailbits >> j) & 1u ? 1.f : 0.f; }
+    }
+
+    // ---- the pyramid step: the lane hosts the output dword of level l+1 whose anchor source column lies in its 4 px ----
+    const bool pyr = raw_next != nullptr;
+    LevelGeom gn = g;
+    int host_gx = -1;
+    uint32_t xw[4] = {0, 0, 0, 0}, xo[4] = {0, 0, 0, 0}, xs[4] = {0, 0, 0, 0};
+    uint32_t nout_off = 0;
+    uint8_t* next0 = nullptr;
+    const uint32_t* yt = nullptr;
+    if (pyr) {
+        gn = P.lv[l + 1];
+        yt = tab + gn.ytab;
+        next0 = raw_next + (int64_t)frame0 * P.raw_frame_bytes + gn.raw_off;
+        if (R.owner) {
+            const uint32_t hv = tab[gn.xinv + R.gdw];
+            if (hv != 0xFFFFFFFFu) host_gx = (int)hv;
+        }
+        if (host_gx >= 0) {
+            const uint32_t* xt = tab + gn.xtab;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t t = xt[min(4 * host_gx + i, gn.w - 1)];
+                const int ox = (int)(t & 0xFFFFu);
+                const uint32_t cx1 = t >> 16;
+                const int lpx = 4 * lane + (ox - 4 * R.gdw);            // local pixel of source column ox in the wave's ring row
+                xw[i] = (256u - cx1) | (cx1 << 16);
+                xo[i] = (uint32_t)(lpx & ~3);
+                xs[i] = 0x0C010C00u + (uint32_t)(lpx & 3) * 0x00010001u;
+            }
+            nout_off = (uint32_t)((int64_t)(R.frame - frame0) * P.raw_frame_bytes + 4 * host_gx);
+        }
+    }
+    int dy_next = 0;                       // next output row of level l+1 (wave-uniform)
+    // the y-table words of 64 output rows at a time, one per lane (a load per row would put an L2 round trip in front of
+    // every output row)
+    int yt_base = 0;
+    uint32_t ytv = pyr ? yt[min(lane, gn.h - 1)] : 0u;
+    uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+    int hprev_row = -1;
+
+    // ---- the 7-row register window; slot = (row + 3) % 7 (static after unrolling by 7) ----
+    uint32_t RC2[7][2], RE[7], RW[7];
+    float RF[7][4];
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+        RC2[u][0] = RC2[u][1] = RE[u] = RW[u] = 0;
+        RF[u][0] = RF[u][1] = RF[u][2] = RF[u][3] = 0.f;
+    }
+
+    auto row_ptr = [&](int t) -> const uint8_t* {                  // level row of ingest index t (REFLECT_101 above / below)
+        const int ry = reflect101(min(t, h + 2), h);
+        return src0 + (int64_t)ry * pitch_in;
+    };
+    // Row loads run TWO groups ahead of the walk and are taken out of their registers in the middle of a group (after the
+    // scoring phase): vmcnt counts loads and stores together, in order, and the compiler cannot know how many stores follow
+    // a load, so taking a row out of its register waits for EVERY vector-memory operation issued so far. At the top of a
+    // group that meant waiting for the stores the pyramid step had issued a moment earlier (a full write round trip per
+    // group); behind the scoring phase the youngest stores are the blurred rows of the walk, thousands of cycles old.
+    uint32_t pre[7], cur[7];
+#pragma unroll
+    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(u - 3) + in_off);
+#pragma unroll
+    for (int u = 0; u < 7; u++) cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
+
+    // per-lane info for whoever processes a queue entry of this lane's pixels: x of px 0 | frame - frame0 | owner
+    const uint32_t linfo = (uint32_t)(4 * max(R.gdw, 0)) | ((uint32_t)(R.frame - frame0) << 11) | (R.owner ? 1u << 31 : 0u);
+
+    int q2n = 0;                 // corners waiting for their lower neighbours' scores (wave-uniform)
+    bool dense = false;          // the corner list overflowed once: NMS scans the score ring from here on
+    int nms_done = fy0 - 1;      // rows <= this have been through NMS
+
+    // ---- candidates leave through an out-list in LDS, 64 at a time, and the global append is split in two: the slice of
+    //      the frame's list is reserved now (one returning atomic per frame in the batch, NOT waited for), the records are
+    //      stored at the NEXT flush, groups later. A wave never sits out an L2 atomic round trip (1-2 us each, once per
+    //      group of rows, was a sixth of this kernel's time). ----
+    int outn = 0;                        // entries in the out-list (wave-uniform)
+    uint32_t p_rec = 0, p_leader = 0, p_rank = 0;   // the batch whose slice has been requested: one entry per lane
+    int p_frame = 0, p_base = 0;
+    bool p_valid = false;
+    auto complete_pending = [&]() {
+        const int base = __builtin_amdgcn_ds_bpermute((int)(p_leader << 2), p_base);
+        if (p_valid) {
+            const int at = base + (int)p_rank;
+            if (at < g.cand_cap) cand[(int64_t)p_frame * P.cand_frame_entries + g.cand_off + at] = p_rec;
+            else atomicOr(err, ERRBIT_CAND_OVERFLOW);
+        }
+        p_valid = false;
+    };
+    auto flush_out = [&](bool all) {
+        wave_sync();
+        while (outn >= (all ? 1 : 64)) {
+            complete_pending();
+            const int nb = min(outn, 64);
+            p_valid = lane < nb;
+            p_rec = p_valid ? s_out[lane] : 0u;
+            p_frame = frame0 + (int)(p_valid ? s_outf[lane] : 0u);
+            // per frame of the batch: leader lane, rank inside the frame's slice, size of the slice; then ONE atomic
+            // instruction in which every leader reserves its frame's slice -- its result is first read at the next flush
+            unsigned long long pend = __builtin_amdgcn_ballot_w64(p_valid);
+            int my_count = 0;
+            while (pend) {
+                const int ld = __ffsll((long long)pend) - 1;
+                const int f = __builtin_amdgcn_readlane(p_frame, ld);
+                const bool mine = p_valid && p_frame == f;
+                const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
+                if (mine) {
+                    p_leader = (uint32_t)ld;
+                    p_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                }
+                if (lane == ld) my_count = __popcll(mm);
+                pend &= ~mm;
+            }
+            if (my_count > 0) p_base = atomicAdd(cand_cnt + p_frame * kLevels + l, my_count);
+            // entries 64.. move to the front
+            const uint32_t mr = lane + 64 < outn ? s_out[lane + 64] : 0u, mf = lane + 64 < outn ? s_outf[lane + 64] : 0u;
+            wave_sync();
+            if (lane + 64 < outn) { s_out[lane] = mr; s_outf[lane] = mf; }
+            outn -= nb;
+            wave_sync();
+        }
+        if (all) complete_pending();
+    };
+
+    const int G = (h + 6 + 6) / 7;        // ingest indices -3 .. h+2
+    // (loads past the last group are issued all the same, clamped to the last row: a condition around them would make the
+    // compiler load into temporaries and copy -- i.e. wait -- at once)
+#pragma unroll
+    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(4 + u) + in_off);
+    for (int gi = 0; gi < G; gi++) {
+        const int t0 = 7 * gi - 3;
+        // ---- rows of this group into the ring; clear the score rows this group will fill ----
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            s_raw[(((t0 + u + 3) & (kRing - 1)) << 6) + lane] = cur[u];
+            s_mapw[(((t0 + u) & (kRing - 1)) << 6) + lane] = 0u;             // score row o = t - 3 (slot (o + 3) & 15)
+        }
+        wave_sync();
+        // y-table window of the pyramid step: refilled here, a whole walk ahead of its first use
+        if (pyr && dy_next + 8 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn.h - 1)]; }
+        PHASE(0);
+
+        // ---- the walk: row pass, column pass + store, compass reject ----
+        uint32_t accw = 0;     // survivors of this group: step u, px j -> bit (j&1 ? 31 : 15) - (j>>1) - 2u
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int t = t0 + u;
+            if (t <= h + 2) {
+                // neighbours' dwords straight from their registers (DPP wave shifts): no LDS round trip in the walk. Lane 0's
+                // left and lane 63's right neighbour do not exist (they read 0): those two lanes only provide pixels.
+                const uint32_t w1 = cur[u];
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138, 0xF, 0xF, true);    // wave_shr:1
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130, 0xF, 0xF, true);    // wave_shl:1
+                RC2[u][0] = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);   // px 0, 1 as int16 pair
+                RC2[u][1] = __builtin_amdgcn_perm(0u, w1, 0x0c030c02u);   // px 2, 3
+                RW[u] = __builtin_amdgcn_alignbyte(w1, w0, 1);     // x-3 .. x
+                RE[u] = __builtin_amdgcn_alignbyte(w2, w1, 3);     // x+3 .. x+6
+                const uint32_t rs0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), KHI,
+                                                            __builtin_amdgcn_udot4(RW[u], KLO, 0u, false), false);
+                const uint32_t rs1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), KHI,
+                                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), KLO, 0u, false), false);
+                const uint32_t rs2 = __builtin_amdgcn_udot4(RE[u], KHI,
+                                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), KLO, 0u, false), false);
+                const uint32_t rs3 = __builtin_amdgcn_udot4(w2, KHI, __builtin_amdgcn_udot4(w1, KLO, 0u, false), false);
+                RF[u][0] = (float)rs0; RF[u][1] = (float)rs1; RF[u][2] = (float)rs2; RF[u][3] = (float)rs3;   // exact: < 2^16
+
+                const int o = t - 3;              // level row whose window [o-3, o+3] is now complete
+                // row o+d of the window lives in slot (u + 4 + d) % 7
+                const int sC = (u + 4) % 7, sM1 = (u + 3) % 7, sP1 = (u + 5) % 7, sM2 = (u + 2) % 7, sP2 = (u + 6) % 7,
+                          sM3 = (u + 1) % 7, sP3 = u;
+                if (o >= 0 && o < h) {
+                    // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u). All values are
+                    // integers * 2^-16 below 2^9, so the fp32 column pass is exact (a partial sum can only be inexact above
+                    // 256.0, which saturates either way); v_cvt_pk_u8_f32 rounds to nearest EVEN (the SIMD path), saturates
+                    // and inserts the byte. Tail pixels (ties UP): x = acc + 0.5 (the bias rides in the first multiply-add),
+                    // floor(x) = x - fract(x), an integer, which the same conversion leaves alone.
+                    constexpr float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
+                    uint32_t outw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float acc = TAIL ? __builtin_fmaf(k0, RF[sC][j], tb[j]) : k0 * RF[sC][j];
+                        acc = __builtin_fmaf(k1, RF[sM1][j] + RF[sP1][j], acc);
+                        acc = __builtin_fmaf(k2, RF[sM2][j] + RF[sP2][j], acc);
+                        acc = __builtin_fmaf(k3, RF[sM3][j] + RF[sP3][j], acc);
+                        if (TAIL) acc = __builtin_fmaf(-__builtin_amdgcn_fractf(acc), tm[j], acc);
+                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc, j, outw);
+                    }
+                    if (R.owner) *reinterpret_cast<uint32_t*>(blur0 + (int64_t)o * g.pitch + out_off) = outw;
+                }
+                if (o >= fy0 && o <= fy1) {
+                    // compass reject, two pixels per packed-int16 op (see k_fast_blur_band): survive iff one of N, S AND one
+                    // of E, W are darker than c - t, or the same with brighter than c + t
+                    uint32_t pass[2];
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {
+                        const uint32_t sl = pr ? 0x0c030c02u : 0x0c010c00u;
+                        const uint32_t c2 = RC2[sC][pr], n2 = RC2[sM3][pr], s2 = RC2[sP3][pr];
+                        const uint32_t e2 = __builtin_amdgcn_perm(0u, RE[sC], sl);
+                        const uint32_t w2p = __builtin_amdgcn_perm(0u, RW[sC], sl);
+                        const uint32_t lo = pk_sub_i16(c2, T2), hi = pk_add_i16(c2, T2);
+                        const uint32_t dk = pk_sub_i16(pk_max_i16(pk_min_i16(n2, s2), pk_min_i16(e2, w2p)), lo);
+                        const uint32_t br = pk_sub_i16(hi, pk_min_i16(pk_max_i16(n2, s2), pk_max_i16(e2, w2p)));
+                        pass[pr] = (dk | br) & (pr ? R.xm1 : R.xm0);
+                    }
+                    accw |= (pass[0] | (pass[1] >> 1)) >> (2 * u);
+                }
+            }
+        }
+
+        PHASE(1);
+        // ---- survivors -> queue -> dense scoring. The queue holds kQ1 entries; the wave's survivors are numbered by a
+        //      prefix sum and go through it in rounds (one round unless the panel is very corner-dense). Corners: score
+        //      into the score ring, (px, row, score) onto the corner list. ----
+        const int o_lo = t0 - 3;                                       // survivor rows of this group: o_lo .. o_lo + 6
+        if (__builtin_amdgcn_ballot_w64(accw != 0)) {
+            const int cnt = __popc(accw);
+            const int incl = wave_scan_incl(cnt);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int my = incl - cnt;                                       // global number of this lane's next survivor
+            for (int r0 = 0; r0 < total; r0 += kQ1) {
+                // append the survivors numbered r0 .. r0 + kQ1 - 1
+                while (accw && my < r0 + kQ1) {
+                    const int b = 31 - __clz(accw);
+                    accw &= ~(1u << b);
+                    const int hi16 = b >> 4, bb = 15 - (b & 15);
+                    const int u = bb >> 1, px = ((bb & 1) << 1) | hi16;
+                    s_q1[my - r0] = (uint32_t)(4 * lane + px) | ((uint32_t)(o_lo + u) << 8);
+                    my++;
+                }
+                wave_sync();
+                const int qn = min(kQ1, total - r0);
+                for (int i0 = 0; i0 < qn; i0 += 64) {
+                    const int i = i0 + lane;
+                    const uint32_t e = i < qn ? s_q1[i] : 0u;
+                    int sc = 0;
+                    if (i < qn) sc = fast_score_ring(s_rawb, (int)(e & 0xFFu), (int)(e >> 8));
+                    const bool corner = i < qn && sc >= thr;
+                    if (corner) s_map[ring_off((int)(e >> 8)) + (e & 0xFFu)] = (uint8_t)sc;
+                    const unsigned long long cm = __builtin_amdgcn_ballot_w64(corner);
+                    if (cm) {
+                        const int at = q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                        if (corner && at < kQ2) s_q2[at] = e | ((uint32_t)sc << 24);
+                        q2n += __popcll(cm);
+                    }
+                }
+                wave_sync();
+            }
+        }
+        wave_sync();
+        PHASE(2);
+        // ---- next group's rows out of their registers (mirrored bytes in place), loads of the group after that ----
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
+            asm volatile("" : "+v"(cur[u]) : : "memory");      // here, not sunk to the loop end behind this group's stores
+        }
+#pragma unroll
+        for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(t0 + 14 + u) + in_off);
+        PHASE(5);
+        if (q2n > kQ2) { dense = true; }
+        if (dense) q2n = 0;
+
+        // ---- 3x3 strict-max NMS + border filter for the rows whose lower neighbours are scored: rows <= o_lo + 5 (all of
+        //      them in the last group). Candidates go to the frame's list through a wave-aggregated append. ----
+        const int nms_hi = gi + 1 < G ? min(o_lo + 5, fy1) : fy1;
+        auto emit = [&](bool keep, int px, int row, int sc) {
+            // (x of the lane's px 0, frame, owner) of the lane that holds the pixel
+            const uint32_t li = __builtin_amdgcn_ds_bpermute((px >> 2) << 2, (int)linfo);
+            const int X = (int)(li & 0x7FFu) + (px & 3);
+            keep = keep && (li >> 31) && X >= kEdgeThreshold && X < w - kEdgeThreshold && row >= kEdgeThreshold && row < h - kEdgeThreshold;
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+            if (km) {
+                if (outn > kOut - 64) flush_out(false);
+                const int at = outn + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                if (keep) {
+                    s_out[at] = (uint32_t)X | ((uint32_t)row << 11) | ((uint32_t)sc << 22);
+                    s_outf[at] = (li >> 11) & 0xFFFFFu;
+                }
+                outn += __popcll(km);
+            }
+        };
+        if (!dense) {
+            int kept = 0;
+            for (int i0 = 0; i0 < q2n; i0 += 64) {
+                const int i = i0 + lane;
+                const uint32_t e = i < q2n ? s_q2[i] : 0u;
+                const int px = (int)(e & 0xFFu), row = (int)((e >> 8) & 0x7FFu), sc = (int)(e >> 24);
+                const bool ready = i < q2n && row <= nms_hi;
+                const bool later = i < q2n && row > nms_hi;
+                bool keep = false;
+                if (ready) {
+                    const uint8_t* a = s_map + ring_off(row - 1) + px; const uint8_t* b = s_map + ring_off(row) + px;
+                    const uint8_t* c = s_map + ring_off(row + 1) + px;
+                    keep = sc > a[-1] && sc > a[0] && sc > a[1] && sc > b[-1] && sc > b[1] && sc > c[-1] && sc > c[0] && sc > c[1];
+                }
+                emit(keep, px, row, sc);
+                const unsigned long long lm = __builtin_amdgcn_ballot_w64(later);
+                if (later) s_q2[kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))] = e;
+                kept += __popcll(lm);
+                wave_sync();
+            }
+            q2n = kept;
+        } else {
+            // corner list overflowed (pathological image): every pixel of the ready rows looks at the score ring
+            for (int row = nms_done + 1; row <= nms_hi; row++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int px = 4 * lane + j;
+                    const uint8_t* b = s_map + ring_off(row) + px;
+                    const int sc = b[0];
+                    bool keep = false;
+                    if (sc > 0 && px >= 1 && px <= 254) {
+                        const uint8_t* a = s_map + ring_off(row - 1) + px; const uint8_t* c = s_map + ring_off(row + 1) + px;
+                        keep = sc > a[-1] && sc > a[0] && sc > a[1] && sc > b[-1] && sc > b[1] && sc > c[-1] && sc > c[0] && sc > c[1];
+                    }
+                    emit(keep, px, row, sc);
+                }
+            }
+        }
+        nms_done = max(nms_done, nms_hi);
+        wave_sync();
+        PHASE(3);
+
+        // ---- a6.1 fused: rows of level l+1 whose two source rows are in the ring now. The lane that hosts an output dword
+        //      blends its 4 pixels from the ring (v_perm + v_dot2_u32_u16, the integers of k_resize_lds); the horizontal
+        //      blend of the lower source row is kept for the next output row, which starts there 5 times out of 6. ----
+        if (pyr) {
+            const int t_last = min(t0 + 6, h - 1);                     // last level row in the ring
+            constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
+            while (dy_next < gn.h && dy_next < yt_base + 64) {
+                dy_next = __builtin_amdgcn_readfirstlane(dy_next);
+                const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)ytv, dy_next - yt_base);
+                const int oy = (int)(ty & 0xFFFFu);
+                const int rb = min(oy + 1, h - 1);
+                if (rb > t_last) break;
+                if (host_gx >= 0) {
+                    const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
+                    const uint8_t* rowa = s_rawb + ring_off(oy);
+                    const uint8_t* rowb = s_rawb + ring_off(rb);
+                    const bool reuse = oy == hprev_row;                 // wave-uniform
+                    // every LDS read of the row is issued before the first use (one round trip, not one per pixel)
+                    uint32_t qb0[4], qb1[4], qa0[4] = {0, 0, 0, 0}, qa1[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t* qb = reinterpret_cast<const uint32_t*>(rowb + xo[i]);
+                        qb0[i] = qb[0]; qb1[i] = qb[1];
+                    }
+                    if (!reuse) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xo[i]);
+                            qa0[i] = qa[0]; qa1[i] = qa[1];
+                        }
+                    }
+                    uint32_t outw = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const us2v wx = __builtin_bit_cast(us2v, xw[i]);
+                        uint32_t h0 = hprev[i];
+                        if (!reuse) h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, __builtin_amdgcn_perm(qa1[i], qa0[i], xs[i])), wx, 0u, false);
+                        const uint32_t bot = __builtin_amdgcn_perm(qb1[i], qb0[i], xs[i]);                 // p10 | p11 << 16
+                        const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, bot), wx, 0u, false);
+                        const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, h0 | (h1 << 16)),
+                                                                  __builtin_bit_cast(us2v, cyp), 32768u, false);   // < 2^24
+                        outw = __builtin_amdgcn_perm(v, outw, put[i]);
+                        hprev[i] = h1;
+                    }
+                    *reinterpret_cast<uint32_t*>(next0 + (int64_t)dy_next * gn.pitch + nout_off) = outw;
+                }
+                hprev_row = rb;
+                dy_next++;
+            }
+        }
+        PHASE(4);
+    }
+    flush_out(true);
+    if (stamps && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) atomicAdd(stamps + k, ph[k]);
+        atomicAdd(stamps + 7, 1ull);
+    }
+#undef PHASE
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
+                                                               uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
+                                                               int* __restrict__ cand_cnt, int* __restrict__ err, int l,
+                                                               int n_frames, const uint32_t* __restrict__ tab,
+                                                               uint8_t* __restrict__ raw_next, int tail_start,
+                                                               unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LevelGeom g = P.lv[l];
+    const int w = g.w, h = g.h;
+    const int D = (w + 3) >> 2, U = D + 2;
+    const int wave_id = (int)blockIdx.x * WPB + wv;
+    const int64_t total = (int64_t)n_frames * U;
+    const int64_t pos0 = (int64_t)wave_id * kOwned - 1;
+    if (pos0 + 1 >= total) return;                       // no barrier anywhere in this kernel: a wave may leave
+    int64_t pos = pos0 + lane;
+    const bool valid = pos >= 0 && pos < total;
+    pos = min(max(pos, (int64_t)0), total - 1);
+    LaneRole R;
+    R.frame = (int)(pos / U);
+    const int j = (int)(pos - (int64_t)R.frame * U);
+    R.gdw = j - 1;
+    const int frame0 = __builtin_amdgcn_readfirstlane(R.frame);
+    const int r4 = w & 3;
+    if (R.gdw < 0 || R.gdw >= D) R.sel = 0x00010203u;                                  // halo: mirrored dword
+    else if (r4 && R.gdw == D - 1) R.sel = r4 == 1 ? 0x00010203u : r4 == 2 ? 0x01020302u : 0x02030201u;
+    else R.sel = 0x03020100u;
+    const bool data = valid && R.gdw >= 0 && R.gdw < D;
+    R.owner = data && lane >= 1 && lane <= kOwned;
+    const bool level_has_kp = (w > 2 * kEdgeThreshold) && (h > 2 * kEdgeThreshold);
+    const int fx0 = kEdgeThreshold - 1, fx1 = w - kEdgeThreshold;                      // inclusive FAST range
+    R.xm0 = R.xm1 = 0;
+    R.tailbits = 0;
+    if (data) {
+        const int x = 4 * R.gdw;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // lane 0 and lane 63 are neighbour providers: only their pixel next to an owned lane is scored (NMS needs it)
+            const bool scored = (lane >= 1 && lane <= kOwned) || (lane == 0 && i == 3) || (lane == 63 && i == 0);
+            if (level_has_kp && scored && x + i >= fx0 && x + i <= fx1) {
+                if (i < 2) R.xm0 |= (i & 1) ? 0x80000000u : 0x00008000u;
+                else R.xm1 |= (i & 1) ? 0x80000000u : 0x00008000u;
+            }
+            if (x + i >= tail_start) R.tailbits |= 1u << i;
+        }
+    }
+    uint8_t* wl = smem + wv * kWaveLds;
+    const bool any_tail = __builtin_amdgcn_ballot_w64(R.tailbits != 0) != 0;
+    if (any_tail) stream_wave<WPB, true>(P, S, raw, blur, cand, cand_cnt, err, l, n_frames, tab, raw_next, wl, wave_id, lane, R, frame0, stamps);
+    else stream_wave<WPB, false>(P, S, raw, blur, cand, cand_cnt, err, l, n_frames, tab, raw_next, wl, wave_id, lane, R, frame0, stamps);
+}
+
+// The batch path takes this kernel when every level is at least 16 px wide and high and the source rows are dword-aligned
+// (the byte-aligned sources of test_batch_device_byte_aligned_images and tiny images stay with the band kernel).
+bool stream_eligible(const Plan& P, const FrameSrc& S) {
+    if (!S.aligned4) return false;
+    for (int l = 0; l < kLevels; l++)
+        if (P.lv[l].w < 16 || P.lv[l].h < 16) return false;
+    return P.stream_ok != 0;
+}
+
+int stream_set_attributes() {
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_stream<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    ARIA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_blur_stream<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    return ARIA_OK;
+}
+
+// Column from which the column filter's ties round UP (the scalar tail of OpenCV's SIMD loop), by blur_tie_mode:
+// 0 = everywhere, 1 = x >= w & ~3 (4-lane vectors), 2 = w & ~7, 3 = w & ~15.
+int blur_tail_start(int tie_mode, int w) {
+    switch (tie_mode) {
+        case 0: return 0;
+        case 2: return w & ~7;
+        case 3: return w & ~15;
+        default: return w & ~3;
+    }
+}
+
+void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                             Profiler* prof, LaunchCtx& ctx) {
+    static const bool want_stamps = [] { const char* e = getenv("ARIA_STREAM_STAMPS"); return e && e[0] == '1'; }();
+    static unsigned long long* d_stamps = nullptr;
+    if (want_stamps && !d_stamps) hipMalloc(&d_stamps, 8 * sizeof(unsigned long long));
+    (void)ctx;
+    static const int wpb = [] { const char* e = getenv("ARIA_STREAM_WPB"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+    for (int l = 0; l < kLevels; l++) {
+        const LevelGeom& g = P.lv[l];
+        const int U = ((g.w + 3) >> 2) + 2;
+        const int64_t total = (int64_t)n_frames * U;
+        const int64_t waves = (total + kOwned - 1) / kOwned;         // wave k owns virtual dwords 62 k .. 62 k + 61
+        const dim3 grid((unsigned)((waves + wpb - 1) / wpb));
+        uint8_t* rn = l + 1 < kLevels ? D.raw : nullptr;
+        const int ts = blur_tail_start(P.tie_mode, g.w);
+#define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), (size_t)N * kWaveLds, st, P, S, D.raw, D.blur, D.cand, \
+                                      D.cand_cnt, D.err, l, n_frames, D.tab, rn, ts, d_stamps)
+        if (d_stamps) hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), st);
+        if (wpb == 1) ARIA_FS_LAUNCH(1); else if (wpb == 2) ARIA_FS_LAUNCH(2); else ARIA_FS_LAUNCH(4);
+#undef ARIA_FS_LAUNCH
+        if (d_stamps) {
+            hipStreamSynchronize(st);
+            unsigned long long hs[8];
+            hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost);
+            const double n = (double)std::max(1ull, hs[7]);
+            fprintf(stderr, "[stream stamps L%d] %llu waves, ticks per wave: ring %.0f walk %.0f append+score %.0f rows-in %.0f nms+emit %.0f pyramid %.0f\n",
+                    l, hs[7], hs[0] / n, hs[1] / n, hs[2] / n, hs[5] / n, hs[3] / n, hs[4] / n);
+        }
+    }
+}
+
+}  // namespace aria

@@ -282,6 +282,8 @@ struct aria_matcher_s {
     int pp_cur = 0;
     // aria_matcher_match_device_async .. aria_matcher_finish: one pending operation
     bool dev_pending = false;
+    hipEvent_t ev_done = nullptr;       // recorded behind the result copy of a pipelined device match (aria_matcher_finish waits
+                                        // for it; the copy that makes the new set resident follows it on the stream)
     uint8_t* d_res = nullptr;       // [16 B header][max_query matches]
     uint8_t* h_res = nullptr;       // pinned
     // the four operations of aria_matcher_match as a hipGraph per ping-pong slot, keyed on the sizes; captured when a key
@@ -455,6 +457,7 @@ int aria_matcher_create(const aria_matcher_config* c, aria_matcher_t* out) {
         m->owns_stream = true;
     }
     int rc = matcher_alloc(m);
+    if (rc == ARIA_OK && hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess) rc = ARIA_E_HIP;
     if (rc != ARIA_OK) { aria_matcher_destroy(m); return rc; }
     *out = m;
     return ARIA_OK;
@@ -466,6 +469,7 @@ void aria_matcher_destroy(aria_matcher_t m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     m->prof_collect();
     for (hipEvent_t e : m->prof_pool) hipEventDestroy(e);
+    if (m->ev_done) hipEventDestroy(m->ev_done);
     matcher_free(m);
     if (m->owns_stream && m->stream) hipStreamDestroy(m->stream);
     delete m;
@@ -538,6 +542,10 @@ struct MatchOps {
     const uint8_t* d_other = nullptr;   // explicit other set (mode 3)
     const int* d_n_new = nullptr;       // device row count of the new set (pipelined form), or nullptr = host-known
     float ratio = 0.75f;
+    // pipelined form: the kernels read the new set where the caller has it, the host waits for ev_done behind the result
+    // copy, and the device copy that makes the set resident comes after that (the caller's next extraction is queued on
+    // the same stream, so it cannot overtake the copy)
+    bool in_place = false;
 };
 
 // kNN-2 in train slices, ratio test + compaction with the slice merge, one copy back ([count][matches]).
@@ -551,9 +559,10 @@ static int enqueue_match_ops(aria_matcher_s* m, const MatchOps& o) {
         d_other = o.d_other;
     }
     if (o.mode <= 1) ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], m->h_pp[cur], (size_t)n_new * 32, hipMemcpyHostToDevice, m->stream));
-    else ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], o.d_new, (size_t)n_new * 32, hipMemcpyDeviceToDevice, m->stream));
-    const uint8_t* d_q = o.new_is_query ? m->d_pp[cur] : d_other;
-    const uint8_t* d_t = o.new_is_query ? d_other : m->d_pp[cur];
+    else if (!o.in_place) ARIA_HIP(hipMemcpyAsync(m->d_pp[cur], o.d_new, (size_t)n_new * 32, hipMemcpyDeviceToDevice, m->stream));
+    const uint8_t* d_new = o.in_place ? o.d_new : m->d_pp[cur];
+    const uint8_t* d_q = o.new_is_query ? d_new : d_other;
+    const uint8_t* d_t = o.new_is_query ? d_other : d_new;
     const int* nq_arr = o.new_is_query ? o.d_n_new : nullptr;
     const int* nt_arr = o.new_is_query ? nullptr : o.d_n_new;
     int nsplit = 1;
@@ -577,7 +586,7 @@ static int enqueue_match_ops(aria_matcher_s* m, const MatchOps& o) {
 static int launch_match_ops(aria_matcher_s* m, const MatchOps& o) {
     static const bool want_graph = [] { const char* e = getenv("ARIA_MATCH_GRAPH"); return !(e && e[0] == '0'); }();
     aria_matcher_s::MatchGraph& G = m->mg[o.cur];
-    const int mode_key = o.mode * 4 + (o.new_is_query ? 0 : 1) + (o.d_n_new ? 2 : 0);
+    const int mode_key = o.mode * 8 + (o.new_is_query ? 0 : 1) + (o.d_n_new ? 2 : 0) + (o.in_place ? 4 : 0);
     const void* pa = o.d_new; const void* pb = o.d_n_new ? (const void*)o.d_n_new : (const void*)o.d_other;
     const bool same = G.nq == o.nq && G.nt == o.nt && G.hit == mode_key && G.ratio == o.ratio && G.pa == pa && G.pb == pb;
     const bool seen = G.seen_nq == o.nq && G.seen_nt == o.nt && G.seen_hit == mode_key && G.seen_ratio == o.ratio &&
@@ -609,6 +618,11 @@ static int launch_match_ops(aria_matcher_s* m, const MatchOps& o) {
         if (rc != ARIA_OK) return rc;
     }
     G.seen_nq = o.nq; G.seen_nt = o.nt; G.seen_hit = mode_key; G.seen_ratio = o.ratio; G.seen_pa = pa; G.seen_pb = pb;
+    if (o.in_place) {
+        ARIA_HIP(hipEventRecord(m->ev_done, m->stream));
+        const int n_new = o.new_is_query ? o.nq : o.nt;
+        ARIA_HIP(hipMemcpyAsync(m->d_pp[o.cur], o.d_new, (size_t)n_new * 32, hipMemcpyDeviceToDevice, m->stream));
+    }
     return ARIA_OK;
 }
 
@@ -709,6 +723,7 @@ int aria_matcher_match_device(aria_matcher_t m, const uint8_t* d_query, int nq, 
 int aria_matcher_match_device_async(aria_matcher_t m, const uint8_t* d_new, const int* d_n_new, int n_new_max, int new_is_query,
                                     float ratio) {
     if (!m || !d_new || !d_n_new || n_new_max < 1) return ARIA_E_INVALID;
+    if (m->dev_pending) return ARIA_E_BUSY;
     ARIA_HIP(hipSetDevice(m->device));
     const int n_res = m->pp_n[m->pp_cur];
     if (n_res < 1) return ARIA_E_INVALID;     // nothing resident to match against (aria_matcher_retain_device first)
@@ -716,6 +731,7 @@ int aria_matcher_match_device_async(aria_matcher_t m, const uint8_t* d_new, cons
     int rc = match_device_setup(m, new_is_query ? d_new : nullptr, new_is_query ? n_new_max : n_res,
                                 new_is_query ? nullptr : d_new, new_is_query ? n_res : n_new_max, ratio, d_n_new, &o);
     if (rc != ARIA_OK) return rc;
+    o.in_place = true;
     rc = launch_match_ops(m, o);
     if (rc != ARIA_OK) return rc;
     m->pp_n[o.cur] = -1; m->pp_host[o.cur] = false; m->pp_cur = o.cur;     // row count: told by aria_matcher_finish
@@ -729,7 +745,7 @@ int aria_matcher_finish(aria_matcher_t m, int n_new, aria_match* matches, int ca
     if (!m->dev_pending) return ARIA_E_NOT_PENDING;
     ARIA_HIP(hipSetDevice(m->device));
     m->dev_pending = false;
-    ARIA_HIP(hipStreamSynchronize(m->stream));
+    ARIA_HIP(hipEventSynchronize(m->ev_done));       // the result copy is done; the copy that keeps the set resident may still run
     m->pp_n[m->pp_cur] = n_new;
     if (n_new == 0) return ARIA_OK;           // CudaMatcher.cpp:35-37 (the kernels saw a zero count and wrote no match)
     return fetch_match_result(m, matches, cap, n_out);

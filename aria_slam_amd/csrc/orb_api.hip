@@ -60,6 +60,10 @@ struct aria_orb_s {
     uint8_t* h_desc = nullptr;
     int* h_count = nullptr;            // = header of h_out
     bool pending = false;
+    // recorded behind the work of every single-frame extraction: the host waits for THIS, not for the whole stream, so that
+    // work a caller queues behind an asynchronous extraction on a shared stream (aria_matcher_match_device_async) does not
+    // delay aria_orb_sync
+    hipEvent_t ev_done = nullptr;
 
     FrameSrc last_src{};
     bool have_last = false;
@@ -196,9 +200,14 @@ int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, i
     FrameSrc S{h->d_img, (int64_t)pitch * height, pitch, 1, (pitch % 16 == 0 && ((int64_t)pitch * height) % 16 == 0) ? 1 : 0};
     h->last_src = S;
     h->have_last = true;
-    if (!timing) return launch_single(h);
+    if (!timing) {
+        rc = launch_single(h);
+        if (rc == ARIA_OK) ARIA_HIP(hipEventRecord(h->ev_done, h->stream));
+        return rc;
+    }
     const auto t1 = std::chrono::steady_clock::now();
     rc = launch_single(h);
+    if (rc == ARIA_OK) ARIA_HIP(hipEventRecord(h->ev_done, h->stream));
     const auto t2 = std::chrono::steady_clock::now();
     h->ht[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
     h->ht[1] += std::chrono::duration<double, std::micro>(t2 - t1).count();
@@ -294,7 +303,7 @@ int enqueue_single_ops(aria_orb_s* h) {
 int finish_single(aria_orb_s* h, aria_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     const bool timing = host_timing();
     const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-    ARIA_HIP(hipStreamSynchronize(h->stream));
+    ARIA_HIP(hipEventSynchronize(h->ev_done));
     const auto t1 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     struct Acc {
         aria_orb_s* h; bool on; std::chrono::steady_clock::time_point a, b;
@@ -400,6 +409,7 @@ int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
         h->owns_stream = true;
     }
     int rc = h->ctx.init(c->device);
+    if (rc == ARIA_OK && hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) rc = ARIA_E_HIP;
     if (rc == ARIA_OK) rc = alloc_scratch(h);
     if (rc != ARIA_OK) { aria_orb_destroy(h); return rc; }
     *out = h;
@@ -414,6 +424,7 @@ void aria_orb_destroy(aria_orb_t h) {
         fprintf(stderr, "[aria host timing] %ld single-frame calls, us per call: staging copy %.1f, enqueue %.1f, wait %.1f, copy out %.1f\n",
                 h->ht_n, h->ht[0] / h->ht_n, h->ht[1] / h->ht_n, h->ht[2] / h->ht_n, h->ht[3] / h->ht_n);
     h->prof.release();
+    if (h->ev_done) hipEventDestroy(h->ev_done);
     drop_graph(h);
     h->ctx.release();
     free_scratch(h);

@@ -87,6 +87,8 @@ struct EnvConfig {
     int pyr_impl;          // 1 = fused in-LDS pyramid (ARIA_PYRAMID_IMPL=fused)
     int rs_impl;           // stand-alone resize pass: 2 dot2 LDS bands, 1 shift/mad LDS bands, 0 direct gathers
     int band_budget_kb, band_qpct0, band_qstep;   // ARIA_BAND_*: <0 / 0 = plan defaults
+    int batch_stream;      // batches take the streaming FAST/blur kernel (fast_blur_stream.hip) where the plan allows it
+                           // (default 1; ARIA_FAST_BLUR_IMPL=band keeps the band kernel)
 };
 const EnvConfig& env_config();
 
@@ -134,6 +136,13 @@ void launch_fast_blur_band(const Plan& P, const FrameSrc& S, const DeviceScratch
 void launch_band2(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof,
                   bool fuse_resize, LaunchCtx& ctx);
 int band2_set_attributes();
+// streaming form of the FAST/blur stage for batches (fast_blur_stream.hip): 8 launches in level order on one stream, each
+// also writing the raw rows of the next level; same contract and same bits as launch_fast_blur_band with fuse_resize
+void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
+                             Profiler* prof, LaunchCtx& ctx);
+bool stream_eligible(const Plan& P, const FrameSrc& S);
+int stream_set_attributes();
+int blur_tail_start(int tie_mode, int w);
 int band_set_attributes();          // hipFuncSetAttribute of the band kernels on the current device (aria_status)
 int band_init_ctx(LaunchCtx& ctx);  // side streams / stamp buffer when the environment asks for them
 int band_side_streams(LaunchCtx& ctx);   // create the per-level side streams + fork/join events (idempotent)

@@ -1053,6 +1053,7 @@ const EnvConfig& env_config() {
         c.band_budget_kb = env_int("ARIA_BAND_BUDGET_KB", 0);
         c.band_qpct0 = env_int("ARIA_BAND_QPCT0", -1);
         c.band_qstep = env_int("ARIA_BAND_QPCT_STEP", -1);
+        c.batch_stream = (c.fast_blur_impl == 2 && !env_is("ARIA_FAST_BLUR_IMPL", 'b') && c.fuse_resize && c.stamp_level < 0) ? 1 : 0;
         return c;
     }();
     return cfg;
@@ -1107,6 +1108,8 @@ int LaunchCtx::init(int dev) {
     int rc = band_set_attributes();
     if (rc != ARIA_OK) return rc;
     rc = band2_set_attributes();
+    if (rc != ARIA_OK) return rc;
+    rc = stream_set_attributes();
     if (rc != ARIA_OK) return rc;
     rc = band_init_ctx(*this);
     if (rc != ARIA_OK) return rc;
@@ -1168,7 +1171,9 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
 
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
-    if (E.fast_blur_impl == 1 && !E.level_streams) {
+    if (E.batch_stream && fuse_resize && stream_eligible(P, S)) {
+        launch_fast_blur_stream(P, S, D, n_frames, st, prof, ctx);
+    } else if (E.fast_blur_impl == 1 && !E.level_streams) {
         launch_band2(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     } else if (E.fast_blur_impl != 0) {
         launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);

@@ -47,6 +47,8 @@ int64_t plan_tab_entries(int width, int height) {
     for (int l = 1; l < kLevels; l++) {
         float inv = 1.0f / layer_scale(l);
         n += round_half_even((float)width * inv) + round_half_even((float)height * inv);
+        const float inv_up = 1.0f / layer_scale(l - 1);
+        n += (round_half_even((float)width * inv_up) + 3) / 4;      // xinv: one entry per dword of the level above
     }
     return n;
 }
@@ -79,6 +81,7 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
     }
 
     int tabpos = 0, tile = 0, cand = 0, sel = 0;
+    P->stream_ok = 1;
     int64_t raw = 0, blur = 0, pix = 0;
     for (int l = 0; l < kLevels; l++) {
         LevelGeom& g = P->lv[l];
@@ -116,6 +119,36 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
             g.ytab = tabpos;
             axis_coeffs(s.h, g.h, tab + tabpos);
             tabpos += g.h;
+            // k_fast_blur_stream's pyramid step: output dword gx (pixels 4 gx .. 4 gx + 3 of this level) is produced by the
+            // lane holding the source dword that contains its ANCHOR column ox(4 gx + 1); that lane reads source columns from
+            // its left neighbour's last two pixels to its right neighbour's last pixel. Table of hosted dwords per source
+            // dword, and the check that every source column of every hosted dword lies in that window (it does for every
+            // scale near 1.2: 4 output pixels span at most 6 source columns; a plan that fails keeps the band kernel).
+            const int Ds = (s.w + 3) / 4, Dn = (g.w + 3) / 4;
+            if (tabpos + Ds > tab_capacity) return ARIA_E_INVALID;
+            g.xinv = tabpos;
+            for (int k = 0; k < Ds; k++) tab[tabpos + k] = 0xFFFFFFFFu;
+            const uint32_t* xt = tab + g.xtab;
+            for (int gx = 0; gx < Dn; gx++) {
+                const int a = (int)(xt[std::min(4 * gx + 1, g.w - 1)] & 0xFFFFu);
+                // host = the source dword of the anchor; a partial last output dword (its anchor index is clamped, so it
+                // can fall into its predecessor's source dword) takes a free neighbour that still sees all its columns
+                int host = -1;
+                const int tries[3] = {a >> 2, (a >> 2) + 1, (a >> 2) - 1};
+                for (int k = 0; k < 3 && host < 0; k++) {
+                    const int gs = tries[k];
+                    if (gs < 0 || gs >= Ds || tab[tabpos + gs] != 0xFFFFFFFFu) continue;
+                    bool ok = true;
+                    for (int i = 0; i < 4; i++) {
+                        const int ox = (int)(xt[std::min(4 * gx + i, g.w - 1)] & 0xFFFFu);
+                        if (ox < 4 * gs - 2 || ox + 1 > 4 * gs + 7) ok = false;
+                    }
+                    if (ok) host = gs;
+                }
+                if (host < 0) P->stream_ok = 0;
+                else tab[tabpos + host] = (uint32_t)gx;
+            }
+            tabpos += Ds;
         }
     }
     // LDS sort capacity of k_select: room for retainBest(2*quota) plus ties at the cut, power of two

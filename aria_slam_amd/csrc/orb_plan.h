@@ -39,7 +39,8 @@ struct LevelGeom {
     int tile_base;     // first tile id of this level in the all-level tile enumeration
     int xtab, ytab;    // offsets (in uint32) of the resize coefficient tables (level >= 1)
     float scale;       // layerScale
-    int _pad;
+    int xinv;          // offset (in uint32) of the streaming kernel's host table (level >= 1): entry g = the dword of THIS level's
+                       // row that source dword g of the level above hosts in the fused pyramid step, or 0xFFFFFFFF
     int64_t raw_off;   // byte offset of the level inside a frame's raw-pyramid block (level 0: caller image)
     int64_t blur_off;  // byte offset inside a frame's blurred-pyramid block
 };
@@ -64,7 +65,7 @@ struct Plan {
     int pyr_ytab_off;         // LDS byte offset of the per-level y-table slice (uint32, kPyrYSlice entries)
     int pyr_p0;               // LDS pitch of the staged level-0 band
     int pyr_xtab_n;           // entries of the x-table copy
-    int _pad2;
+    int stream_ok;            // the streaming FAST/blur kernel's pyramid-step ownership rule holds for this plan's tables
     int64_t raw_frame_bytes;
     int64_t blur_frame_bytes;
     int64_t pixels_total;     // P of BASELINE.md section 3

@@ -225,7 +225,9 @@ int aria_matcher_resident_rows(aria_matcher_t m);
  * on the matcher's stream without waiting -- behind the extraction when both handles were given the same stream -- and
  * aria_matcher_finish synchronises, is told the new set's row count (which the caller knows by then) and returns the
  * matches. new_is_query: 1 = query is the new set, 0 = query is the resident set. One pending operation per handle
- * (ARIA_E_BUSY); aria_matcher_finish without one returns ARIA_E_NOT_PENDING. */
+ * (ARIA_E_BUSY); aria_matcher_finish without one returns ARIA_E_NOT_PENDING. The kernels read the new set where it lies
+ * and the copy that keeps it resident is queued BEHIND the result copy (aria_matcher_finish does not wait for it): whatever
+ * overwrites d_new next must be queued on the same stream -- true for the extractor handle that shares it. */
 int aria_matcher_match_device_async(aria_matcher_t m, const uint8_t* d_new, const int* d_n_new, int n_new_max, int new_is_query,
                                     float ratio);
 int aria_matcher_finish(aria_matcher_t m, int n_new, aria_match* matches, int cap, int* n_out);

@@ -896,7 +896,8 @@ def test_device_handoff_equals_oracle(aria, oracle, torch_cuda):
                 if prev is not None:
                     q, t = (fr, prev) if i % 2 == 0 else (prev, fr)
                     want = oracle.match_ratio(q["descriptors"], t["descriptors"], 0.75)
-                    assert len(want) > 50 and got.tobytes() == want.tobytes(), (shared, i)
+                    assert got.tobytes() == want.tobytes(), (shared, i)
+                    assert len(want) > 50 or i % 2 == 0         # frames 2k, 2k+1 show the same scene; 2k+1, 2k+2 do not
                 assert m.resident_rows() == n
                 prev = fr
             # explicit form: both sets given; the query becomes the resident one
