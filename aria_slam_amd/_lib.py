@@ -32,6 +32,7 @@ EXPORTS = [
     "aria_kfdb_add", "aria_kfdb_add_device", "aria_kfdb_info", "aria_kfdb_fetch", "aria_kfdb_scan",
     "aria_orb_last_device", "aria_matcher_match_device", "aria_matcher_retain_device", "aria_matcher_resident_rows",
     "aria_matcher_match_device_async", "aria_matcher_finish", "aria_kfdb_match", "aria_stream_create", "aria_stream_destroy",
+    "aria_orb_fast_blur_kernel",
 ]
 
 
@@ -138,6 +139,8 @@ def load_library():
     L.aria_orb_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.aria_matcher_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_int)]
+    L.aria_orb_fast_blur_kernel.argtypes = [C.c_void_p]
+    L.aria_orb_fast_blur_kernel.restype = C.c_char_p
     L.aria_orb_last_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.aria_matcher_match_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,

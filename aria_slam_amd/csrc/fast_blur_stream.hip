@@ -128,21 +128,42 @@ struct LaneRole {
     bool owner;           // stores blurred pixels and reports candidates
 };
 
+// Everything the kernel needs about ONE level launch, as plain scalars (a Plan indexed by a run-time level lives in kernarg
+// memory and every use of a field in the walk became a scalar load + wait: the kernel is short of SGPRs).
+struct StreamArgs {
+    const uint8_t* src;       // level l, frame 0, row 0
+    uint8_t* blur;            // blurred level l of frame 0
+    uint8_t* next;            // raw level l+1 of frame 0, or nullptr
+    uint32_t* cand;           // candidate list of (frame 0, level l)
+    int* cand_cnt;            // candidate counter of (frame 0, level l); frame stride kLevels
+    int* err;
+    const uint32_t* xt;       // tables of level l+1
+    const uint32_t* yt;
+    const uint32_t* xinv;
+    int64_t src_fstride, blur_fstride, next_fstride;     // bytes between frames
+    int cand_fstride;         // entries between frames
+    int cand_cap;
+    int src_pitch, blur_pitch, next_pitch;
+    int w, h, next_w, next_h;
+    int n_frames, thr, tail_start;
+};
+
 }  // namespace
 
 template <int WPB, bool TAIL>
-__device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, const uint8_t* __restrict__ raw,
-                                            uint8_t* __restrict__ blur, uint32_t* __restrict__ cand, int* __restrict__ cand_cnt,
-                                            int* __restrict__ err, const int l, const int n_frames,
-                                            const uint32_t* __restrict__ tab, uint8_t* __restrict__ raw_next,
-                                            uint8_t* __restrict__ wl, const int wave_id, const int lane, const LaneRole R,
+__device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __restrict__ wl, const int lane, const LaneRole R,
                                             const int frame0, unsigned long long* __restrict__ stamps) {
-    // diagnostic (ARIA_STREAM_STAMPS=1): s_memtime ticks per phase, summed over the waves of the launch
+    // diagnostic builds only (-DARIA_DIAG, ARIA_STREAM_STAMPS=1): s_memtime ticks per phase, summed over the waves of the
+    // launch. Not in the product build: the accumulators alone are 16 SGPRs of a kernel that is short of them.
+#ifdef ARIA_DIAG
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 #define PHASE(k) do { if (stamps) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tlast; tlast = tn; } } while (0)
-    const LevelGeom g = P.lv[l];
-    const int w = g.w, h = g.h;
+#else
+    (void)stamps;
+#define PHASE(k) do { } while (0)
+#endif
+    const int w = A.w, h = A.h;
     uint32_t* s_raw = reinterpret_cast<uint32_t*>(wl + kHdrBytes);                 // [kRing][64] dwords
     uint8_t* s_rawb = wl + kHdrBytes;
     uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
@@ -153,9 +174,9 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
     uint32_t* s_outf = s_out + kOut;
 
     // ---- addresses: wave-uniform 64-bit bases + 32-bit lane offsets ----
-    int pitch_in;
-    const uint8_t* src0 = raw_level_ptr(P, S, raw, frame0, l, pitch_in);           // level l of frame0
-    const int64_t fstride_in = l == 0 ? S.frame_stride : P.raw_frame_bytes;
+    const int pitch_in = A.src_pitch;
+    const uint8_t* src0 = A.src + (int64_t)frame0 * A.src_fstride;                 // level l of frame0
+    const int64_t fstride_in = A.src_fstride;
     const int r4 = w & 3, D = (w + 3) >> 2;
     int xload;
     if (R.gdw < 0) xload = 1;
@@ -163,12 +184,12 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
     else if (r4 && R.gdw == D - 1) xload = w - 4;
     else xload = 4 * R.gdw;
     const uint32_t in_off = (uint32_t)((int64_t)(R.frame - frame0) * fstride_in + xload);
-    uint8_t* blur0 = blur + (int64_t)frame0 * P.blur_frame_bytes + g.blur_off;
-    const uint32_t out_off = (uint32_t)((int64_t)(R.frame - frame0) * P.blur_frame_bytes + 4 * max(R.gdw, 0));
+    uint8_t* blur0 = A.blur + (int64_t)frame0 * A.blur_fstride;
+    const uint32_t out_off = (uint32_t)((int64_t)(R.frame - frame0) * A.blur_fstride + 4 * max(R.gdw, 0));
 
     // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); FAST is needed on that region + 1 ring
     const int fy0 = kEdgeThreshold - 1, fy1 = h - kEdgeThreshold;
-    const int thr = P.fast_threshold;
+    const int thr = A.thr;
     const uint32_t T2 = (uint32_t)thr * 0x00010001u;
     const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
     const uint32_t KHI = 49u | (34u << 8) | (18u << 16);                 // taps x+1..x+3 (x+4 weight 0)
@@ -181,26 +202,25 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
     }
 
     // ---- the pyramid step: the lane hosts the output dword of level l+1 whose anchor source column lies in its 4 px ----
-    const bool pyr = raw_next != nullptr;
-    LevelGeom gn = g;
+    const bool pyr = A.next != nullptr;
+    const int gn_w = A.next_w, gn_h = A.next_h;
     int host_gx = -1;
     uint32_t xw[4] = {0, 0, 0, 0}, xo[4] = {0, 0, 0, 0}, xs[4] = {0, 0, 0, 0};
     uint32_t nout_off = 0;
     uint8_t* next0 = nullptr;
     const uint32_t* yt = nullptr;
     if (pyr) {
-        gn = P.lv[l + 1];
-        yt = tab + gn.ytab;
-        next0 = raw_next + (int64_t)frame0 * P.raw_frame_bytes + gn.raw_off;
+        yt = A.yt;
+        next0 = A.next + (int64_t)frame0 * A.next_fstride;
         if (R.owner) {
-            const uint32_t hv = tab[gn.xinv + R.gdw];
+            const uint32_t hv = A.xinv[R.gdw];
             if (hv != 0xFFFFFFFFu) host_gx = (int)hv;
         }
         if (host_gx >= 0) {
-            const uint32_t* xt = tab + gn.xtab;
+            const uint32_t* xt = A.xt;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t t = xt[min(4 * host_gx + i, gn.w - 1)];
+                const uint32_t t = xt[min(4 * host_gx + i, gn_w - 1)];
                 const int ox = (int)(t & 0xFFFFu);
                 const uint32_t cx1 = t >> 16;
                 const int lpx = 4 * lane + (ox - 4 * R.gdw);            // local pixel of source column ox in the wave's ring row
@@ -208,14 +228,14 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
                 xo[i] = (uint32_t)(lpx & ~3);
                 xs[i] = 0x0C010C00u + (uint32_t)(lpx & 3) * 0x00010001u;
             }
-            nout_off = (uint32_t)((int64_t)(R.frame - frame0) * P.raw_frame_bytes + 4 * host_gx);
+            nout_off = (uint32_t)((int64_t)(R.frame - frame0) * A.next_fstride + 4 * host_gx);
         }
     }
     int dy_next = 0;                       // next output row of level l+1 (wave-uniform)
     // the y-table words of 64 output rows at a time, one per lane (a load per row would put an L2 round trip in front of
     // every output row)
     int yt_base = 0;
-    uint32_t ytv = pyr ? yt[min(lane, gn.h - 1)] : 0u;
+    uint32_t ytv = pyr ? yt[min(lane, gn_h - 1)] : 0u;
     uint32_t hprev[4] = {0u, 0u, 0u, 0u};
     int hprev_row = -1;
 
@@ -262,8 +282,8 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
         const int base = __builtin_amdgcn_ds_bpermute((int)(p_leader << 2), p_base);
         if (p_valid) {
             const int at = base + (int)p_rank;
-            if (at < g.cand_cap) cand[(int64_t)p_frame * P.cand_frame_entries + g.cand_off + at] = p_rec;
-            else atomicOr(err, ERRBIT_CAND_OVERFLOW);
+            if (at < A.cand_cap) A.cand[(int64_t)p_frame * A.cand_fstride + at] = p_rec;
+            else atomicOr(A.err, ERRBIT_CAND_OVERFLOW);
         }
         p_valid = false;
     };
@@ -291,7 +311,7 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
                 if (lane == ld) my_count = __popcll(mm);
                 pend &= ~mm;
             }
-            if (my_count > 0) p_base = atomicAdd(cand_cnt + p_frame * kLevels + l, my_count);
+            if (my_count > 0) p_base = atomicAdd(A.cand_cnt + p_frame * kLevels, my_count);
             // entries 64.. move to the front
             const uint32_t mr = lane + 64 < outn ? s_out[lane + 64] : 0u, mf = lane + 64 < outn ? s_outf[lane + 64] : 0u;
             wave_sync();
@@ -317,7 +337,7 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
         }
         wave_sync();
         // y-table window of the pyramid step: refilled here, a whole walk ahead of its first use
-        if (pyr && dy_next + 8 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn.h - 1)]; }
+        if (pyr && dy_next + 8 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn_h - 1)]; }
         PHASE(0);
 
         // ---- the walk: row pass, column pass + store, compass reject ----
@@ -365,7 +385,7 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
                         if (TAIL) acc = __builtin_fmaf(-__builtin_amdgcn_fractf(acc), tm[j], acc);
                         outw = __builtin_amdgcn_cvt_pk_u8_f32(acc, j, outw);
                     }
-                    if (R.owner) *reinterpret_cast<uint32_t*>(blur0 + (int64_t)o * g.pitch + out_off) = outw;
+                    if (R.owner) { uint8_t* orow = blur0 + (int64_t)o * A.blur_pitch; *reinterpret_cast<uint32_t*>(orow + out_off) = outw; }
                 }
                 if (o >= fy0 && o <= fy1) {
                     // compass reject, two pixels per packed-int16 op (see k_fast_blur_band): survive iff one of N, S AND one
@@ -507,7 +527,7 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
         if (pyr) {
             const int t_last = min(t0 + 6, h - 1);                     // last level row in the ring
             constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
-            while (dy_next < gn.h && dy_next < yt_base + 64) {
+            while (dy_next < gn_h && dy_next < yt_base + 64) {
                 dy_next = __builtin_amdgcn_readfirstlane(dy_next);
                 const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)ytv, dy_next - yt_base);
                 const int oy = (int)(ty & 0xFFFFu);
@@ -545,7 +565,7 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
                         outw = __builtin_amdgcn_perm(v, outw, put[i]);
                         hprev[i] = h1;
                     }
-                    *reinterpret_cast<uint32_t*>(next0 + (int64_t)dy_next * gn.pitch + nout_off) = outw;
+                    { uint8_t* orow = next0 + (int64_t)dy_next * A.next_pitch; *reinterpret_cast<uint32_t*>(orow + nout_off) = outw; }
                 }
                 hprev_row = rb;
                 dy_next++;
@@ -554,29 +574,25 @@ __device__ __forceinline__ void stream_wave(const Plan& P, const FrameSrc& S, co
         PHASE(4);
     }
     flush_out(true);
+#ifdef ARIA_DIAG
     if (stamps && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 6; k++) atomicAdd(stamps + k, ph[k]);
         atomicAdd(stamps + 7, 1ull);
     }
+#endif
 #undef PHASE
 }
 
 template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
-                                                               uint8_t* __restrict__ blur, uint32_t* __restrict__ cand,
-                                                               int* __restrict__ cand_cnt, int* __restrict__ err, int l,
-                                                               int n_frames, const uint32_t* __restrict__ tab,
-                                                               uint8_t* __restrict__ raw_next, int tail_start,
-                                                               unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(StreamArgs A, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const LevelGeom g = P.lv[l];
-    const int w = g.w, h = g.h;
+    const int w = A.w, h = A.h;
     const int D = (w + 3) >> 2, U = D + 2;
     const int wave_id = (int)blockIdx.x * WPB + wv;
-    const int64_t total = (int64_t)n_frames * U;
+    const int64_t total = (int64_t)A.n_frames * U;
     const int64_t pos0 = (int64_t)wave_id * kOwned - 1;
     if (pos0 + 1 >= total) return;                       // no barrier anywhere in this kernel: a wave may leave
     int64_t pos = pos0 + lane;
@@ -607,13 +623,13 @@ __global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(Plan P, FrameSrc 
                 if (i < 2) R.xm0 |= (i & 1) ? 0x80000000u : 0x00008000u;
                 else R.xm1 |= (i & 1) ? 0x80000000u : 0x00008000u;
             }
-            if (x + i >= tail_start) R.tailbits |= 1u << i;
+            if (x + i >= A.tail_start) R.tailbits |= 1u << i;
         }
     }
     uint8_t* wl = smem + wv * kWaveLds;
     const bool any_tail = __builtin_amdgcn_ballot_w64(R.tailbits != 0) != 0;
-    if (any_tail) stream_wave<WPB, true>(P, S, raw, blur, cand, cand_cnt, err, l, n_frames, tab, raw_next, wl, wave_id, lane, R, frame0, stamps);
-    else stream_wave<WPB, false>(P, S, raw, blur, cand, cand_cnt, err, l, n_frames, tab, raw_next, wl, wave_id, lane, R, frame0, stamps);
+    if (any_tail) stream_wave<WPB, true>(A, wl, lane, R, frame0, stamps);
+    else stream_wave<WPB, false>(A, wl, lane, R, frame0, stamps);
 }
 
 // The batch path takes this kernel when every level is at least 16 px wide and high and the source rows are dword-aligned
@@ -645,7 +661,11 @@ int blur_tail_start(int tie_mode, int w) {
 
 void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
                              Profiler* prof, LaunchCtx& ctx) {
+#ifdef ARIA_DIAG
     static const bool want_stamps = [] { const char* e = getenv("ARIA_STREAM_STAMPS"); return e && e[0] == '1'; }();
+#else
+    const bool want_stamps = false;
+#endif
     static unsigned long long* d_stamps = nullptr;
     if (want_stamps && !d_stamps) hipMalloc(&d_stamps, 8 * sizeof(unsigned long long));
     (void)ctx;
@@ -656,10 +676,19 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
         const int64_t total = (int64_t)n_frames * U;
         const int64_t waves = (total + kOwned - 1) / kOwned;         // wave k owns virtual dwords 62 k .. 62 k + 61
         const dim3 grid((unsigned)((waves + wpb - 1) / wpb));
-        uint8_t* rn = l + 1 < kLevels ? D.raw : nullptr;
-        const int ts = blur_tail_start(P.tie_mode, g.w);
-#define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), (size_t)N * kWaveLds, st, P, S, D.raw, D.blur, D.cand, \
-                                      D.cand_cnt, D.err, l, n_frames, D.tab, rn, ts, d_stamps)
+        StreamArgs A{};
+        if (l == 0) { A.src = S.img; A.src_fstride = S.frame_stride; A.src_pitch = S.row_stride; }
+        else { A.src = D.raw + g.raw_off; A.src_fstride = P.raw_frame_bytes; A.src_pitch = g.pitch; }
+        A.blur = D.blur + g.blur_off; A.blur_fstride = P.blur_frame_bytes; A.blur_pitch = g.pitch;
+        A.cand = D.cand + g.cand_off; A.cand_fstride = P.cand_frame_entries; A.cand_cap = g.cand_cap;
+        A.cand_cnt = D.cand_cnt + l; A.err = D.err;
+        A.w = g.w; A.h = g.h; A.n_frames = n_frames; A.thr = P.fast_threshold; A.tail_start = blur_tail_start(P.tie_mode, g.w);
+        if (l + 1 < kLevels) {
+            const LevelGeom& gn = P.lv[l + 1];
+            A.next = D.raw + gn.raw_off; A.next_fstride = P.raw_frame_bytes; A.next_pitch = gn.pitch; A.next_w = gn.w; A.next_h = gn.h;
+            A.xt = D.tab + gn.xtab; A.yt = D.tab + gn.ytab; A.xinv = D.tab + gn.xinv;
+        }
+#define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), (size_t)N * kWaveLds, st, A, d_stamps)
         if (d_stamps) hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), st);
         if (wpb == 1) ARIA_FS_LAUNCH(1); else if (wpb == 2) ARIA_FS_LAUNCH(2); else ARIA_FS_LAUNCH(4);
 #undef ARIA_FS_LAUNCH

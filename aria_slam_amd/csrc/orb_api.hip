@@ -557,6 +557,8 @@ long long aria_orb_slow_path_blocks(aria_orb_t h, int reset) {
     return n;
 }
 
+const char* aria_orb_fast_blur_kernel(aria_orb_t h) { return h ? h->ctx.last_fast_blur : ""; }
+
 int aria_orb_set_stage_event(aria_orb_t h, int stage, void* event) {
     if (!h || stage < 0 || stage >= ARIA_ORB_STAGES) return ARIA_E_INVALID;
     if (stage != STAGE_SELECT) return ARIA_E_INVALID;       // the one point a caller has asked for so far

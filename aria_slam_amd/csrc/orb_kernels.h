@@ -111,6 +111,7 @@ struct LaunchCtx {
     // entry point for its last pass only
     hipEvent_t stage_event[4] = {};
     bool stage_events_armed = false;
+    const char* last_fast_blur = "";   // name of the FAST/blur kernel the most recent pass launched (aria_orb_fast_blur_kernel)
     hipStream_t side[kLevels] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {}, ev_lvl[kLevels] = {};
     unsigned long long* d_band_stamps = nullptr;

@@ -1161,6 +1161,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     }
     if (latency) {
         // single-frame latency schedule: resize chain and the 8 FAST/blur launches overlap (fast_blur_band.hip)
+        ctx.last_fast_blur = "k_fast_blur_band";
         launch_pyramid_and_band_latency(P, S, D, n_frames, st, prof, ctx);
     } else {
     if (!fuse_resize) {
@@ -1172,12 +1173,16 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
     if (E.batch_stream && fuse_resize && stream_eligible(P, S)) {
+        ctx.last_fast_blur = "k_fast_blur_stream";
         launch_fast_blur_stream(P, S, D, n_frames, st, prof, ctx);
     } else if (E.fast_blur_impl == 1 && !E.level_streams) {
+        ctx.last_fast_blur = "k_band2";
         launch_band2(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     } else if (E.fast_blur_impl != 0) {
+        ctx.last_fast_blur = "k_fast_blur_band";
         launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     } else {
+        ctx.last_fast_blur = "k_fast_blur";
         launch_fast_blur_tile(P, S, D, n_frames, st, prof);
     }
     if (prof) prof->end(st);

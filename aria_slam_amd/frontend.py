@@ -142,6 +142,10 @@ class OrbHipExtractor:
         """Rows the largest frame of the last checked batch call needed when kp_cap was too small (else 0)."""
         return self._L.aria_orb_rows_needed(self._h)
 
+    def fast_blur_kernel(self):
+        """Name of the FAST/blur kernel the most recent pass launched."""
+        return self._L.aria_orb_fast_blur_kernel(self._h).decode()
+
     def slow_path_blocks(self, reset=False):
         return self._L.aria_orb_slow_path_blocks(self._h, int(reset))
 

@@ -50,12 +50,12 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("ARIA_CPU_BASELINE_THREADS", "16"))))
 
 
-def load_traffic(chunk):
-    """HBM bytes per frame of k_fast_blur_band from the committed PMC passes (tools/pmc_traffic.sh), or None."""
-    for name in ("pmc_traffic_%d.json" % chunk, "pmc_traffic_1024.json"):
+def load_traffic(chunk, kernel="k_fast_blur_band"):
+    """HBM bytes per frame of the FAST/blur kernel from the committed PMC passes (tools/pmc_traffic.sh), or None."""
+    for name in ("pmc_traffic_r3.json", "pmc_traffic_%d.json" % chunk, "pmc_traffic_1024.json"):
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
-            k = json.load(open(f))["kernels"].get("k_fast_blur_band")
+            k = json.load(open(f))["kernels"].get(kernel)
             if k:
                 return k["fetch_bytes_per_frame"] + k["write_bytes_per_frame"], name
     return None, None
@@ -673,7 +673,8 @@ def main():
         frames_per_launch = prof_frames / max(launches["fast_blur"], 1)
         fb_bytes_per_launch = alg["fast_blur"] * frames_per_launch
         achieved = fb_bytes_per_launch / (fb_ms_per_launch * 1e-3) / 1e9 if fb_ms_per_launch > 0 else 0.0
-        traffic_pf, traffic_src = load_traffic(args.chunk)
+        fb_kernel = ext.fast_blur_kernel()
+        traffic_pf, traffic_src = load_traffic(args.chunk, fb_kernel)
         ext_ms = sum(all_ms[k] for k in ("resize", "fast_blur", "select", "describe")) * (prof_frames / max(frames_all, 1))
         pair_ops = 512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))   # 2 * 256 * sum(nq * nt)
         if stage_ms.get("knn2"):
@@ -696,9 +697,9 @@ def main():
         fused_us = 1e3 * (all_ms["fast_blur"] + all_ms["describe"]) / max(frames_all, 1)
         fused_gbs = b_fused / (fused_us * 1e-6) / 1e9 if fused_us > 0 else 0.0
         roofline = {
-            "bound": "hbm", "kernel": "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level + bilinear resize to the next level, "
-                                      "fused; 8 level launches per pass)" if fused_pyramid else
-                                      "k_fast_blur_band (FAST-9 + NMS + 7x7 Gaussian of one level, fused; 8 level launches per pass)",
+            "bound": "hbm", "kernel": fb_kernel + (" (FAST-9 + NMS + 7x7 Gaussian of one level + bilinear resize to the next level, "
+                                                   "fused; 8 level launches per pass)" if fused_pyramid else
+                                                   " (FAST-9 + NMS + 7x7 Gaussian of one level, fused; 8 level launches per pass)"),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": (int(traffic_pf * frames_per_launch) if traffic_pf and (W, H, NF) == (640, 480, 2000) else None),

@@ -146,6 +146,10 @@ void* aria_orb_stream(aria_orb_t h);
  * aria_orb_sync / aria_orb_check read the device state; the handle enlarges the queue for later calls by itself. */
 long long aria_orb_slow_path_blocks(aria_orb_t h, int reset);
 
+/* Diagnostics: name of the FAST/blur kernel the handle's most recent pass launched ("k_fast_blur_stream" for batches whose
+ * plan and source alignment allow the streaming kernel, "k_fast_blur_band" for the single-frame schedule and the rest). */
+const char* aria_orb_fast_blur_kernel(aria_orb_t h);
+
 /* Per-stage device timing for bench.py's roofline figure (no reference counterpart): when enabled, HIP events
  * are recorded on the handle's stream around each stage of every internal pass.
  * Stages: 0 pyramid resize (7 launches per pass), 1 FAST+NMS+blur, 2 select (retainBest+Harris), 3 describe
