@@ -6,7 +6,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libaria_orb_hip.so")
+# ARIA_ORB_HIP_LIBRARY: tests and profiling tools point this binding at the variants build (libaria_orb_hip_variants.so,
+# `make -C aria_slam_amd/csrc variants`), the only library that knows the ARIA_* kernel / tuning switches. The product
+# library itself reads no environment variable.
+_SO = os.environ.get("ARIA_ORB_HIP_LIBRARY") or os.path.join(_HERE, "libaria_orb_hip.so")
+_SO_VARIANTS = os.path.join(_HERE, "libaria_orb_hip_variants.so")
 
 # byte-for-byte aria::core::KeyPoint / aria::core::Match (reference include/core/Types.hpp:9-15, :97-101)
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -39,7 +43,7 @@ EXPORTS = [
 class OrbConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("stream", C.c_void_p), ("max_width", C.c_int),
                 ("max_height", C.c_int), ("max_features", C.c_int), ("max_batch", C.c_int),
-                ("blur_tie_mode", C.c_int), ("cand_cap_scale", C.c_int)]
+                ("blur_tie_mode", C.c_int), ("cand_cap_scale", C.c_int), ("level_size_mode", C.c_int)]
 
 
 class MatcherConfig(C.Structure):
@@ -69,6 +73,12 @@ def build_library(force=False):
         os.remove(_SO)
     subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
     return _SO
+
+
+def build_variants_library():
+    """Compile libaria_orb_hip_variants.so (-DARIA_VARIANTS: superseded kernels + ARIA_* switches) and return its path."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "variants"])
+    return _SO_VARIANTS
 
 
 _lib = None

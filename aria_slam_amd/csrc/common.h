@@ -3,11 +3,21 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "aria_orb_hip.h"
 
 namespace aria {
+
+// The product library (libaria_orb_hip.so) reads NO environment variable: every variant kernel and every tuning or
+// experiment switch exists only in the variants build (-DARIA_VARIANTS: libaria_orb_hip_variants.so, built by
+// tests/test_gpu_variants.py and the profiling tools under tools/), where this is getenv.
+#ifdef ARIA_VARIANTS
+inline const char* aria_getenv(const char* name) { return std::getenv(name); }
+#else
+inline const char* aria_getenv(const char*) { return nullptr; }
+#endif
 
 // thread-local text of the last HIP failure, surfaced through aria_last_hip_error()
 char* last_hip_error_buf();

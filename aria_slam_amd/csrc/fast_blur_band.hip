@@ -42,7 +42,7 @@ constexpr int kStripRows = kBandR + 8;     // staged rows yb-4 .. yb+R+3 of a st
 //    columns too (a 533-px level: 128 lanes + 21 fix-up columns instead of 134 lanes in 192 threads).
 static int band_lanes(const Plan& P, int w, bool trim) {
     const int wq = (w + 3) & ~3;
-    if (P.tie_mode != 1) return wq >> 2;
+    if (P.tie_mode == 0) return wq >> 2;
     const int full = (w & 3) ? (w >> 2) : (wq >> 2);
     if (!trim || w <= 2 * kEdgeThreshold) return full;
     const int fast_lanes = ((w - kEdgeThreshold) >> 2) + 1;       // lanes whose columns reach into x <= w - 31
@@ -473,11 +473,13 @@ __global__ __launch_bounds__(512) void k_fast_blur_band(Plan P, FrameSrc S, cons
     //      here in integers from the staged pixels (filter.simd.hpp SymmColumnFilter) and overwrite the bytes stored above. ----
     // The same loop computes every column the walk left out (x >= 4 lpr: band_lanes' trimmed blur-only columns), with the
     // SIMD path's round-half-to-even for x < (w & ~3).
-    if (TIE_EVEN && 4 * lpr < w && !(ablate & 2)) {
+    // blur_tie_mode 2 / 3 (vector body ends at w & ~7 / w & ~15): the same loop, started at the first tail column.
+    const int tail_start = P.tie_mode == 2 ? (w & ~7) : P.tie_mode == 3 ? (w & ~15) : (w & ~3);
+    if (TIE_EVEN && min(4 * lpr, tail_start) < w && !(ablate & 2)) {
         // thread -> (column, part of the block's rows): it walks its rows top to bottom with the seven horizontal sums of
         // the window in registers, so a staged pixel is read once per column it contributes to (7 byte reads + the
         // vertical pass per output pixel, not 49)
-        const int xb = 4 * lpr, nt = w - xb, x_even_end = w & ~3;
+        const int xb = min(4 * lpr, tail_start), nt = w - xb, x_even_end = tail_start;
         const int np = max(1, min(RB, 64 / nt));                 // row parts: one wave's worth of threads
         const int rows_pp = (RB + np - 1) / np;
         uint8_t* blf = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
@@ -705,7 +707,7 @@ static void band_launch_level(const Plan& P, const FrameSrc& S, const DeviceScra
 #define ARIA_FB_LAUNCH(T, N) ARIA_LAUNCH(prof, (k_fast_blur_band<T, N>), grid, dim3(c.nthr), c.lds, s, P, S, D.raw, D.blur, D.cand, \
                                          D.cand_cnt, D.err, l, c.nb, c.qcap, ablate, stp, D.err + 1, D.tab, \
                                          (fuse_resize && l + 1 < kLevels) ? D.raw : (uint8_t*)nullptr, ball)
-    if (P.tie_mode == 1) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
+    if (P.tie_mode != 0) { if (c.nb == 1) ARIA_FB_LAUNCH(1, 1); else ARIA_FB_LAUNCH(1, 0); }
     else { if (c.nb == 1) ARIA_FB_LAUNCH(0, 1); else ARIA_FB_LAUNCH(0, 0); }
 #undef ARIA_FB_LAUNCH
     if (stp) {   // diagnostic: print mean phase lengths of this launch
@@ -744,7 +746,7 @@ void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const Dev
     // ARIA_LATENCY_FORK=1 (experiment, measured slower: 188 vs 135 us per frame, a second branch in the graph costs more
     // in cross-queue signalling than the overlap gains): level 0 needs nothing but the source frame, so its strips run
     // on a side stream beside the pyramid kernel and levels 1..7 follow the pyramid.
-    static const bool fork = [] { const char* e = getenv("ARIA_LATENCY_FORK"); return e && e[0] == '1'; }();
+    static const bool fork = [] { const char* e = aria_getenv("ARIA_LATENCY_FORK"); return e && e[0] == '1'; }();
     auto band = [&](int l_lo, int l_hi, hipStream_t s) {
         BandAll ba{};
         size_t lds = 0;
@@ -767,7 +769,7 @@ void launch_pyramid_and_band_latency(const Plan& P, const FrameSrc& S, const Dev
         ba.first[kLevels] = total;
         if (total == 0) return;
         const dim3 grid(total, n_frames);
-        if (P.tie_mode == 1)
+        if (P.tie_mode != 0)
             ARIA_LAUNCH(prof, (k_fast_blur_band<1, 1>), grid, dim3(nthr), lds, s, P, S, D.raw, D.blur, D.cand, D.cand_cnt, D.err, -1, 1, 0,
                         0, (unsigned long long*)nullptr, D.err + 1, D.tab, (uint8_t*)nullptr, ba);
         else

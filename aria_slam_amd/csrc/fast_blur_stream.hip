@@ -632,10 +632,11 @@ __global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(StreamArgs A, uns
     else stream_wave<WPB, false>(A, wl, lane, R, frame0, stamps);
 }
 
-// The batch path takes this kernel when every level is at least 16 px wide and high and the source rows are dword-aligned
-// (the byte-aligned sources of test_batch_device_byte_aligned_images and tiny images stay with the band kernel).
+// The batch path takes this kernel when every level is at least 16 px wide and high (tiny images stay with the band
+// kernel). Source rows need no alignment: every lane's row load is a dword load of any byte address (the mirrored halo
+// loads are unaligned by construction).
 bool stream_eligible(const Plan& P, const FrameSrc& S) {
-    if (!S.aligned4) return false;
+    (void)S;
     for (int l = 0; l < kLevels; l++)
         if (P.lv[l].w < 16 || P.lv[l].h < 16) return false;
     return P.stream_ok != 0;
@@ -662,14 +663,14 @@ int blur_tail_start(int tie_mode, int w) {
 void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st,
                              Profiler* prof, LaunchCtx& ctx) {
 #ifdef ARIA_DIAG
-    static const bool want_stamps = [] { const char* e = getenv("ARIA_STREAM_STAMPS"); return e && e[0] == '1'; }();
+    static const bool want_stamps = [] { const char* e = aria_getenv("ARIA_STREAM_STAMPS"); return e && e[0] == '1'; }();
 #else
     const bool want_stamps = false;
 #endif
     static unsigned long long* d_stamps = nullptr;
     if (want_stamps && !d_stamps) hipMalloc(&d_stamps, 8 * sizeof(unsigned long long));
     (void)ctx;
-    static const int wpb = [] { const char* e = getenv("ARIA_STREAM_WPB"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+    static const int wpb = [] { const char* e = aria_getenv("ARIA_STREAM_WPB"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
     for (int l = 0; l < kLevels; l++) {
         const LevelGeom& g = P.lv[l];
         const int U = ((g.w + 3) >> 2) + 2;

@@ -282,7 +282,7 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
                       const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
                       uint2* keys, int maxq, double ratio, int* good, int max_train, int* gate) {
     if (nq_max <= 0 || n_pairs <= 0) return;
-    static const int force_nc = [] { const char* e = getenv("ARIA_KNN_NC"); return e ? atoi(e) : 0; }();
+    static const int force_nc = [] { const char* e = aria_getenv("ARIA_KNN_NC"); return e ? atoi(e) : 0; }();
     const bool wide = max_train > kNarrowMax;      // only built in the 256-query form
     // 512-query workgroups amortise the train staging and the A-fragment reads over twice the MFMAs, but need enough
     // workgroups to fill 256 CUs x 2; small jobs (a single frame pair) take the 256-query form

@@ -38,6 +38,7 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     return r;
 }
 
+#ifdef ARIA_VARIANTS      // the vector-ALU kNN-2 (round 1's kernel): variants build only, ARIA_KNN_IMPL=valu
 template <int MODE>   // 0: store the two keys per query; 1: count queries passing the double-precision ratio test
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed,
                                               const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed,
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
     }
 }
 
+#endif  // ARIA_VARIANTS
+
 // CudaMatcher.cpp:59-67: fp32 Lowe test, matches appended in query order. One workgroup per pair; the ordered
 // compaction uses wave ballots + popcount prefixes.
 // qflags / tflags (optional): per-keypoint "lies in a dynamic object" flags of the query / train frame of every pair
@@ -153,58 +156,72 @@ __global__ __launch_bounds__(NT) void k_ratio_compact(const uint2* __restrict__ 
     const uint2* kk = keys + (int64_t)pair * maxq;
     aria_match* o = out + (int64_t)pair * cap;
     int base = 0;
-    for (int q0 = 0; q0 < nq; q0 += NT) {
-        const int qi = q0 + tid;
-        bool ok = false;
-        uint2 k = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (qi < nq) {
-            k = kk[qi];
-            // train slices of the latency schedule (one pair): two smallest of all. All slices are requested before the
-            // first is merged (at most kKnnSplitMax - 1 loads in flight): on an idle chip every dependent round trip is a
-            // microsecond, and this kernel is on the frame-at-a-time path
-            if (nsplit > 1) {
-                uint2 o[kKnnSplitMax - 1];
+    // QP queries per thread and trip: their key loads (all slices) are requested together -- on an idle chip every dependent
+    // round trip is a microsecond and the single-pair form (NT = 1024) is on the frame-at-a-time path: 2000 queries are one
+    // trip of one round trip instead of two
+    constexpr int QP = NT == 1024 ? 2 : 1;
+    for (int q0 = 0; q0 < nq; q0 += NT * QP) {
+        uint2 k[QP];
+        uint2 os[QP][kKnnSplitMax - 1];
 #pragma unroll
-                for (int j = 0; j < kKnnSplitMax - 1; j++) o[j] = kk[(int64_t)min(1 + j, nsplit - 1) * maxq + qi];   // clamped loads past the last slice are not merged
+        for (int p = 0; p < QP; p++) {
+            const int qi = q0 + p * NT + tid;
+            k[p] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (qi < nq) {
+                k[p] = kk[qi];
+                if (nsplit > 1) {
 #pragma unroll
-                for (int j = 0; j < kKnnSplitMax - 1; j++) {
-                    if (1 + j < nsplit) {
-                        const uint32_t lo = min(k.x, o[j].x);
-                        k.y = min(max(k.x, o[j].x), min(k.y, o[j].y));
-                        k.x = lo;
-                    }
+                    for (int j = 0; j < kKnnSplitMax - 1; j++) os[p][j] = kk[(int64_t)min(1 + j, nsplit - 1) * maxq + qi];   // clamped loads past the last slice are not merged
                 }
             }
-            if (ratio == 0.0f) ok = k.x != 0xFFFFFFFFu;   // IMatcher.hpp:18 "0.0 = disabled"
-            else ok = k.y != 0xFFFFFFFFu && (float)(k.x >> 16) < ratio * (float)(k.y >> 16);
-            if (ok && qflags && (qflags[(int64_t)pair * flag_stride + qi] | tflags[(int64_t)pair * flag_stride + (k.x & 0xFFFFu)])) {
-                ok = false;
-                atomicAdd(&s_f, 1);
-            }
         }
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) s_w[wv] = __popcll(m);
-        __syncthreads();
-        int off = base, tot = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            if (w < wv) off += s_w[w];
-            tot += s_w[w];
-        }
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        if (ok) {
-            if (off < cap) {
-                aria_match mm;
-                mm.query_idx = qi;
-                mm.train_idx = (int)(k.x & 0xFFFFu);
-                mm.distance = (float)(k.x >> 16);
-                o[off] = mm;
-            } else {
-                atomicOr(err, ERRBIT_MATCHCAP);
+        for (int p = 0; p < QP; p++) {
+            const int qi = q0 + p * NT + tid;
+            bool ok = false;
+            if (qi < nq) {
+                // train slices of the latency schedule (one pair): two smallest of all
+                if (nsplit > 1) {
+#pragma unroll
+                    for (int j = 0; j < kKnnSplitMax - 1; j++) {
+                        if (1 + j < nsplit) {
+                            const uint32_t lo = min(k[p].x, os[p][j].x);
+                            k[p].y = min(max(k[p].x, os[p][j].x), min(k[p].y, os[p][j].y));
+                            k[p].x = lo;
+                        }
+                    }
+                }
+                if (ratio == 0.0f) ok = k[p].x != 0xFFFFFFFFu;   // IMatcher.hpp:18 "0.0 = disabled"
+                else ok = k[p].y != 0xFFFFFFFFu && (float)(k[p].x >> 16) < ratio * (float)(k[p].y >> 16);
+                if (ok && qflags && (qflags[(int64_t)pair * flag_stride + qi] | tflags[(int64_t)pair * flag_stride + (k[p].x & 0xFFFFu)])) {
+                    ok = false;
+                    atomicAdd(&s_f, 1);
+                }
             }
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) s_w[wv] = __popcll(m);
+            __syncthreads();
+            int off = base, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                if (w < wv) off += s_w[w];
+                tot += s_w[w];
+            }
+            off += __popcll(m & ((1ull << lane) - 1ull));
+            if (ok) {
+                if (off < cap) {
+                    aria_match mm;
+                    mm.query_idx = qi;
+                    mm.train_idx = (int)(k[p].x & 0xFFFFu);
+                    mm.distance = (float)(k[p].x >> 16);
+                    o[off] = mm;
+                } else {
+                    atomicOr(err, ERRBIT_MATCHCAP);
+                }
+            }
+            base += tot;
+            __syncthreads();
         }
-        base += tot;
-        __syncthreads();
     }
     if (tid == 0) {
         nout[pair] = min(base, cap);
@@ -344,6 +361,10 @@ namespace {
 void launch_knn2(aria_matcher_s* m, int mode, int nq_max, int n_pairs, const uint8_t* q, const int* nq_arr, int nq_fixed,
                  const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* keys,
                  int maxq, double ratio, int* good, int max_train) {
+#ifndef ARIA_VARIANTS
+    launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
+                     keys, maxq, ratio, good, max_train, m->d_err + 1);
+#else
     if (!m->knn_valu) {
         launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
                          keys, maxq, ratio, good, max_train, m->d_err + 1);
@@ -356,6 +377,7 @@ void launch_knn2(aria_matcher_s* m, int mode, int nq_max, int n_pairs, const uin
     else
         hipLaunchKernelGGL(k_knn2<1>, grid, dim3(256), 0, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
                            t_stride, keys, maxq, ratio, good);
+#endif
 }
 
 int ensure_keys(aria_matcher_s* m, size_t entries) {
@@ -448,7 +470,7 @@ int aria_matcher_create(const aria_matcher_config* c, aria_matcher_t* out) {
     m->device = c->device;
     m->max_query = c->max_query;
     m->max_train = c->max_train;
-    { const char* e = getenv("ARIA_KNN_IMPL"); m->knn_valu = e && std::strcmp(e, "valu") == 0; }
+    { const char* e = aria_getenv("ARIA_KNN_IMPL"); m->knn_valu = e && std::strcmp(e, "valu") == 0; }
     if (c->stream) {
         m->stream = (hipStream_t)c->stream;
     } else {
@@ -584,7 +606,7 @@ static int enqueue_match_ops(aria_matcher_s* m, const MatchOps& o) {
 // Replays the captured graph of these operations when the key (sizes, ratio, mode, baked-in pointers) repeats for the
 // slot; captures it when a key shows up the second time in a row; eager launches otherwise.
 static int launch_match_ops(aria_matcher_s* m, const MatchOps& o) {
-    static const bool want_graph = [] { const char* e = getenv("ARIA_MATCH_GRAPH"); return !(e && e[0] == '0'); }();
+    static const bool want_graph = [] { const char* e = aria_getenv("ARIA_MATCH_GRAPH"); return !(e && e[0] == '0'); }();
     aria_matcher_s::MatchGraph& G = m->mg[o.cur];
     const int mode_key = o.mode * 8 + (o.new_is_query ? 0 : 1) + (o.d_n_new ? 2 : 0) + (o.in_place ? 4 : 0);
     const void* pa = o.d_new; const void* pb = o.d_n_new ? (const void*)o.d_n_new : (const void*)o.d_other;

@@ -28,7 +28,7 @@ struct aria_orb_s {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 0;
+    int max_w = 0, max_h = 0, max_features = 0, max_batch = 1, tie_mode = 1, cand_cap_scale = 0, level_size_mode = 0;
     int band_qpct0 = 10;            // survivor-queue size of the band kernel at level 0 (% of a workgroup's pixels); self-tuned
     long long slow_blocks = 0;      // band-kernel workgroups that overflowed their queue since the last reset
     int last_n = -1;                // keypoints of the last completed single-frame extraction (still in the pinned buffers)
@@ -124,7 +124,7 @@ int alloc_scratch(aria_orb_s* h) {
     h->tab_host.assign((size_t)tabn, 0);
     int used = 0;
     int rc = build_plan(h->max_w, h->max_h, h->max_features, h->cand_cap_scale, h->tie_mode, &mp, h->tab_host.data(),
-                        (int)tabn, &used);
+                        (int)tabn, &used, h->level_size_mode);
     if (rc != ARIA_OK) return rc;
     const size_t B = (size_t)h->max_batch;
     h->kp_cap = mp.sel_frame_entries;
@@ -171,7 +171,7 @@ int ensure_plan(aria_orb_s* h, int w, int ht) {
     }
     int used = 0;
     int rc = build_plan(w, ht, h->max_features, h->cand_cap_scale, h->tie_mode, &h->plan, h->tab_host.data(),
-                        (int)h->tab_host.size(), &used);
+                        (int)h->tab_host.size(), &used, h->level_size_mode);
     if (rc != ARIA_OK) return rc;
     h->plan.band_qpct0 = h->band_qpct0;
     if (used > 0)
@@ -186,7 +186,7 @@ int ensure_plan(aria_orb_s* h, int w, int ht) {
 }
 
 int launch_single(aria_orb_s* h);
-static bool host_timing() { static const bool on = getenv("ARIA_HOST_TIMING") != nullptr; return on; }
+static bool host_timing() { static const bool on = aria_getenv("ARIA_HOST_TIMING") != nullptr; return on; }
 
 int enqueue_single(aria_orb_s* h, const uint8_t* image, int width, int height, int stride) {
     if (!image || stride < width) return ARIA_E_INVALID;
@@ -243,14 +243,14 @@ int enqueue_single_ops(aria_orb_s* h);
 // Replays (capturing it first when the plan or the buffers changed) the single-frame sequence as a hipGraph. Eager
 // launches when profiling brackets are on (they synchronise the stream) or ARIA_SINGLE_GRAPH=0.
 int launch_single(aria_orb_s* h) {
-    static const bool want_graph = [] { const char* e = getenv("ARIA_SINGLE_GRAPH"); return !(e && e[0] == '0'); }();
+    static const bool want_graph = [] { const char* e = aria_getenv("ARIA_SINGLE_GRAPH"); return !(e && e[0] == '0'); }();
     const bool diag = env_config().stamp_level >= 0 || env_config().sel_stamps || env_config().desc_stamps;
-    static const bool eager_latency = [] { const char* e = getenv("ARIA_SINGLE_GRAPH"); return e && e[0] == 'e'; }();
+    static const bool eager_latency = [] { const char* e = aria_getenv("ARIA_SINGLE_GRAPH"); return e && e[0] == 'e'; }();
     if (eager_latency && !h->prof.enabled && band_side_streams(h->ctx) == ARIA_OK) {
         h->ctx.schedule = 1;            // ARIA_SINGLE_GRAPH=eager: the latency schedule's launches without the graph
         return enqueue_single_ops(h);
     }
-    if (diag && getenv("ARIA_DIAG_LATENCY") && band_side_streams(h->ctx) == ARIA_OK) {
+    if (diag && aria_getenv("ARIA_DIAG_LATENCY") && band_side_streams(h->ctx) == ARIA_OK) {
         h->ctx.schedule = 1;            // phase stamps of the latency schedule's kernels: same launches, eagerly
         return enqueue_single_ops(h);
     }
@@ -377,6 +377,7 @@ void aria_orb_default_config(aria_orb_config* c) {
     c->max_batch = 1;
     c->blur_tie_mode = 1;
     c->cand_cap_scale = 0;
+    c->level_size_mode = 0;
 }
 
 int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
@@ -399,7 +400,9 @@ int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
     h->max_h = c->max_height;
     h->max_features = c->max_features;
     h->max_batch = c->max_batch;
-    h->tie_mode = c->blur_tie_mode ? 1 : 0;
+    if (c->blur_tie_mode < 0 || c->blur_tie_mode > 3 || c->level_size_mode < 0 || c->level_size_mode > 1) { delete h; return ARIA_E_INVALID; }
+    h->tie_mode = c->blur_tie_mode;
+    h->level_size_mode = c->level_size_mode;
     h->cand_cap_scale = c->cand_cap_scale > 0 ? c->cand_cap_scale : 0;
     if (c->stream) {
         h->stream = (hipStream_t)c->stream;

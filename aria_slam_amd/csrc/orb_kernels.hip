@@ -1028,8 +1028,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static bool env_is(const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; }
+static int env_int(const char* name, int dflt) { const char* e = aria_getenv(name); return e ? atoi(e) : dflt; }
+static bool env_is(const char* name, char c) { const char* e = aria_getenv(name); return e && e[0] == c; }
 
 // The environment is read once per process (thread-safe static initialisation) and never written again.
 const EnvConfig& env_config() {
@@ -1048,8 +1048,8 @@ const EnvConfig& env_config() {
         c.rs_impl = env_is("ARIA_RESIZE_IMPL", 'd') ? 0 : env_is("ARIA_RESIZE_IMPL", 'l') ? 1 : 2;
         // A separate resize pass runs only when asked for (ARIA_RESIZE_FUSE=0, ARIA_RESIZE_IMPL, ARIA_PYRAMID_IMPL) or when
         // the band kernel is not the one in use (tile kernel, per-level side streams).
-        c.fuse_resize = (c.fast_blur_impl != 0 && !env_is("ARIA_RESIZE_FUSE", '0') && !getenv("ARIA_RESIZE_IMPL") &&
-                         !getenv("ARIA_PYRAMID_IMPL") && !c.level_streams) ? 1 : 0;
+        c.fuse_resize = (c.fast_blur_impl != 0 && !env_is("ARIA_RESIZE_FUSE", '0') && !aria_getenv("ARIA_RESIZE_IMPL") &&
+                         !aria_getenv("ARIA_PYRAMID_IMPL") && !c.level_streams) ? 1 : 0;
         c.band_budget_kb = env_int("ARIA_BAND_BUDGET_KB", 0);
         c.band_qpct0 = env_int("ARIA_BAND_QPCT0", -1);
         c.band_qstep = env_int("ARIA_BAND_QPCT_STEP", -1);
@@ -1107,8 +1107,10 @@ int LaunchCtx::init(int dev) {
     if (int prc = pyramid_set_attributes(); prc != ARIA_OK) return prc;
     int rc = band_set_attributes();
     if (rc != ARIA_OK) return rc;
+#ifdef ARIA_VARIANTS
     rc = band2_set_attributes();
     if (rc != ARIA_OK) return rc;
+#endif
     rc = stream_set_attributes();
     if (rc != ARIA_OK) return rc;
     rc = band_init_ctx(*this);
@@ -1138,8 +1140,8 @@ static bool latency_schedule(const LaunchCtx& ctx, const Profiler* prof) {
 bool latency_zero_copy(const Plan& P, const LaunchCtx& ctx, const Profiler* prof) {
     // opt-in (ARIA_ZERO_COPY=1): measured slower than the upload node, 128 vs 125 us per frame -- the band staging of the
     // pyramid kernel turns into host-link round trips
-    static const bool off = [] { const char* e = getenv("ARIA_ZERO_COPY"); return !(e && e[0] == '1'); }();
-    const char* f = getenv("ARIA_LATENCY_FORK");        // (the forked level-0 launch reads the device copy at once)
+    static const bool off = [] { const char* e = aria_getenv("ARIA_ZERO_COPY"); return !(e && e[0] == '1'); }();
+    const char* f = aria_getenv("ARIA_LATENCY_FORK");        // (the forked level-0 launch reads the device copy at once)
     return !off && !(f && f[0] == '1') && ctx.host_img != nullptr && latency_schedule(ctx, prof) && pyramid_fused_available(P);
 }
 
@@ -1164,26 +1166,30 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         ctx.last_fast_blur = "k_fast_blur_band";
         launch_pyramid_and_band_latency(P, S, D, n_frames, st, prof, ctx);
     } else {
-    if (!fuse_resize) {
+#ifdef ARIA_VARIANTS
+    if (!fuse_resize) {         // stand-alone pyramid pass: variants build only (the product always fuses it)
         if (prof) prof->begin(STAGE_RESIZE, st);
         launch_pyramid_pass(P, S, D, n_frames, st, prof);
         if (prof) prof->end(st);
     }
+#endif
 
     // ---- a6.2 + a6.3 + a6.7 FAST, NMS, blur ----
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
     if (E.batch_stream && fuse_resize && stream_eligible(P, S)) {
         ctx.last_fast_blur = "k_fast_blur_stream";
         launch_fast_blur_stream(P, S, D, n_frames, st, prof, ctx);
-    } else if (E.fast_blur_impl == 1 && !E.level_streams) {
+#ifdef ARIA_VARIANTS
+    } else if (E.fast_blur_impl == 1 && !E.level_streams && P.tie_mode <= 1) {
         ctx.last_fast_blur = "k_band2";
         launch_band2(P, S, D, n_frames, st, prof, fuse_resize, ctx);
-    } else if (E.fast_blur_impl != 0) {
-        ctx.last_fast_blur = "k_fast_blur_band";
-        launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);
-    } else {
+    } else if (E.fast_blur_impl == 0 && P.tie_mode <= 1) {    // (the variant kernels know blur_tie_mode 0 and 1 only)
         ctx.last_fast_blur = "k_fast_blur";
         launch_fast_blur_tile(P, S, D, n_frames, st, prof);
+#endif
+    } else {
+        ctx.last_fast_blur = "k_fast_blur_band";
+        launch_fast_blur_band(P, S, D, n_frames, st, prof, fuse_resize, ctx);
     }
     if (prof) prof->end(st);
     }

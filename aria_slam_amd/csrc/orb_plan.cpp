@@ -9,6 +9,13 @@
 
 #include "aria_orb_hip.h"
 
+// (see common.h: the product build reads no environment variable)
+#ifdef ARIA_VARIANTS
+static const char* aria_getenv(const char* n) { return std::getenv(n); }
+#else
+static const char* aria_getenv(const char*) { return nullptr; }
+#endif
+
 namespace aria {
 
 namespace {
@@ -50,11 +57,11 @@ int64_t plan_tab_entries(int width, int height) {
         const float inv_up = 1.0f / layer_scale(l - 1);
         n += (round_half_even((float)width * inv_up) + 3) / 4;      // xinv: one entry per dword of the level above
     }
-    return n;
+    return n + 4 * kLevels;       // (level_size_mode 1 can make a level one pixel larger)
 }
 
 int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie_mode, Plan* P,
-               uint32_t* tab, int tab_capacity, int* tab_used) {
+               uint32_t* tab, int tab_capacity, int* tab_used, int level_size_mode) {
     if (width < 16 || height < 16 || width > kMaxDim || height > kMaxDim || nfeatures < 0) return ARIA_E_INVALID;
     *P = Plan{};
     P->width = width;
@@ -89,6 +96,10 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
         float inv = 1.0f / g.scale;   // orb.cpp detectAndCompute: Size sz(cvRound(cols*inv_scale), cvRound(rows*inv_scale))
         g.w = round_half_even((float)width * inv);
         g.h = round_half_even((float)height * inv);
+        if (level_size_mode == 1) {     // the other reading of orb.cpp: one float division
+            g.w = round_half_even((float)width / g.scale);
+            g.h = round_half_even((float)height / g.scale);
+        }
         if (g.w < 8 || g.h < 8) return ARIA_E_INVALID;
         g.pitch = align_up(g.w, 16);
         g.quota = quota[l];
@@ -233,7 +244,7 @@ int build_pyramid_bands(Plan* P, const uint32_t* tab, int* out, int out_capacity
     // three workgroups share a CU, the former choice -- 121-123). The halo (one extra source row per level, amplified by 1.2
     // per level) makes thin bands recompute a lot, which is why the batch path does not use this kernel at all.
     const int lds_max = 150 * 1024;
-    if (const char* e = getenv("ARIA_PYR_BH")) {
+    if (const char* e = aria_getenv("ARIA_PYR_BH")) {
         const int n = pyramid_bands_for(P, tab, std::max(8, atoi(e) & ~7), out, out_capacity);
         if (n > 0 && P->pyr_lds_bytes <= lds_max) return n;
     }

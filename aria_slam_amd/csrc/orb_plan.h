@@ -52,7 +52,7 @@ struct Plan {
     int total_tiles;
     int cand_frame_entries;   // candidate entries per frame (all levels)
     int sel_frame_entries;    // selection entries per frame (all levels)
-    int tie_mode;
+    int tie_mode;             // 0: column-filter ties round up everywhere; 1 / 2 / 3: to even for x < (w & ~3 / ~7 / ~15), up in the tail
     int fast_threshold;
     int sort_cap;             // power of two in [kSortCapMin, kSortCapMax]
     // band kernel tuning: survivor-queue size = min(50, band_qpct0 + band_qstep * level) % of a workgroup's pixels;
@@ -72,8 +72,9 @@ struct Plan {
 };
 
 // Host-side construction (orb_plan.cpp). tab receives the packed resize coefficients (ofs | c1 << 16).
+// tie_mode: blur_tie_mode of aria_orb_config (0..3); level_size_mode: 0 = cvRound(dim * (1.0f / scale)), 1 = cvRound(dim / scale)
 int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie_mode, Plan* plan,
-               uint32_t* tab, int tab_capacity, int* tab_used);
+               uint32_t* tab, int tab_capacity, int* tab_used, int level_size_mode = 0);
 int64_t plan_tab_entries(int width, int height);
 // Per band and level: {comp_lo, comp_n, own_lo, own_n} = rows the band computes / rows it also writes to HBM.
 // Returns the number of ints written (pyr_nbands * kLevels * 4). Fills plan->pyr_*.

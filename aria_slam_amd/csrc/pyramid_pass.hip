@@ -423,6 +423,9 @@ void launch_pyramid_level(const Plan& P, const FrameSrc& S, const DeviceScratch&
     ARIA_LAUNCH(prof, k_resize, dim3((items + 255) / 256, n_frames), dim3(256), lds2, st, P, S, D.raw, D.tab, l);
 }
 
+#ifdef ARIA_VARIANTS
+// the stand-alone pyramid pass in its measured forms (variants build only: the product fuses the pyramid step into the
+// FAST/blur launches and uses launch_pyramid_level / k_pyramid in the single-frame schedule)
 void launch_pyramid_pass(const Plan& P, const FrameSrc& S, const DeviceScratch& D, int n_frames, hipStream_t st, Profiler* prof) {
     const EnvConfig& E = env_config();
     const int pyr_impl = E.pyr_impl;   // 0 = one resize launch per level (default); 1 = fused LDS pyramid (ARIA_PYRAMID_IMPL=fused,
@@ -456,5 +459,6 @@ void launch_pyramid_pass(const Plan& P, const FrameSrc& S, const DeviceScratch& 
     }
 
 }
+#endif  // ARIA_VARIANTS
 
 }  // namespace aria

@@ -32,7 +32,7 @@ class OrbHipExtractor:
     """Replaces aria::adapters::gpu::OrbCudaExtractor (reference include/adapters/gpu/OrbCudaExtractor.hpp)."""
 
     def __init__(self, max_features=1000, stream=None, device=0, max_width=640, max_height=480, max_batch=1,
-                 blur_tie_mode=1, cand_cap_scale=0):
+                 blur_tie_mode=1, cand_cap_scale=0, level_size_mode=0):
         self._L = _lib.load_library()
         cfg = _lib.OrbConfig()
         self._L.aria_orb_default_config(C.byref(cfg))
@@ -43,6 +43,7 @@ class OrbHipExtractor:
         cfg.max_batch = max_batch
         cfg.blur_tie_mode = blur_tie_mode
         cfg.cand_cap_scale = cand_cap_scale
+        cfg.level_size_mode = level_size_mode
         h = C.c_void_p()
         check(self._L.aria_orb_create(C.byref(cfg), C.byref(h)), "aria_orb_create")
         self._h = h

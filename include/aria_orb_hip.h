@@ -74,9 +74,14 @@ typedef struct {
     int   max_height;
     int   max_features;    /* nfeatures (OrbCudaExtractor.hpp:12 default 1000)                              */
     int   max_batch;       /* frames processed per internal pass of the batch entry point (>= 1)            */
-    int   blur_tie_mode;   /* 1 (default): OpenCV SIMD column-filter rounding; 0: ties-up everywhere        */
+    int   blur_tie_mode;   /* rounding of exact ties in the 7x7 blur's column filter, which in OpenCV depends on the SIMD
+                            * width its dispatcher picks: 1 (default) ties to even for columns x < (w & ~3) and up in the
+                            * scalar tail; 2 / 3: the vector body ends at w & ~7 / w & ~15; 0: ties up everywhere       */
     int   cand_cap_scale;  /* 0 (default): FAST candidate lists sized for the worst case, cannot overflow;
                               > 0: cap each level's list at cand_cap_scale * quota entries to save HBM          */
+    int   level_size_mode; /* pyramid level size: 0 (default) cvRound(dim * (1.0f / scale)), 1 cvRound(dim / scale) -- the
+                              two readings of cv::ORB's sizing; they differ for few sizes (tools/level_size_sweep.py,
+                              profiles/level_size_sweep.txt: none of the BASELINE sizes)                            */
 } aria_orb_config;
 
 const char* aria_status_string(int status);

@@ -19,7 +19,7 @@ MATCH_DTYPE = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("distance",
 
 class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
-                ("fast_threshold", C.c_int), ("blur_tie_mode", C.c_int)]
+                ("fast_threshold", C.c_int), ("blur_tie_mode", C.c_int), ("level_size_mode", C.c_int)]
 
 
 def build():
@@ -60,11 +60,12 @@ def _i32(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
 
 
-def default_params(nfeatures=1000, blur_tie_mode=1):
+def default_params(nfeatures=1000, blur_tie_mode=1, level_size_mode=0):
     p = Params()
     lib().orc_default_params(C.byref(p))
     p.nfeatures = nfeatures
     p.blur_tie_mode = blur_tie_mode
+    p.level_size_mode = level_size_mode
     return p
 
 

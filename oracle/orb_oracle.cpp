@@ -119,6 +119,7 @@ void orc_default_params(orc_params* p) {
     p->nlevels = 8;            // :38
     p->fast_threshold = 20;    // :44
     p->blur_tie_mode = 1;
+    p->level_size_mode = 0;
 }
 
 const int* orc_bit_pattern_31(void) { return kPattern; }
@@ -135,6 +136,11 @@ float orc_layer_scale(const orc_params* p, int level) {
 void orc_level_size(const orc_params* p, int w, int h, int level, int* lw, int* lh) {
     float scale = orc_layer_scale(p, level);
     float inv_scale = 1.0f / scale;
+    if (p->level_size_mode == 1) {      // the other reading of orb.cpp: one float division instead of reciprocal + multiply
+        *lw = cv_round((float)w / scale);
+        *lh = cv_round((float)h / scale);
+        return;
+    }
     *lw = cv_round((float)w * inv_scale);
     *lh = cv_round((float)h * inv_scale);
 }
@@ -266,7 +272,8 @@ void orc_gaussian_kernel7_fixed(int* k7) {
  *     exact for every sum < 2^24; larger sums saturate to 255 either way. Vector steps go down to 4
  *     lanes, so the body covers columns x < (w & ~3);
  *   - scalar tail (FixedPtCastEx<int,uchar>): (sum + 32768) >> 16 (ties up).
- * tie_mode 1 reproduces that split, tie_mode 0 uses ties-up everywhere.                                 */
+ * tie_mode 1 reproduces that split, tie_mode 0 uses ties-up everywhere; tie_mode 2 / 3 put the end of the
+ * vector body at w & ~7 / w & ~15 (a dispatch whose narrowest vector step is 8 / 16 lanes).            */
 void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int tie_mode) {
     int k[7];
     orc_gaussian_kernel7_fixed(k);
@@ -277,14 +284,14 @@ void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* 
             for (int i = -3; i <= 3; i++) s += k[i + 3] * src[(size_t)y * sstride + reflect101(x + i, w)];
             rows[(size_t)y * w + x] = s;
         }
-    int body = w & ~3;
+    int body = tie_mode == 0 ? 0 : tie_mode == 2 ? (w & ~7) : tie_mode == 3 ? (w & ~15) : (w & ~3);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             int64_t s = 0;
             for (int j = -3; j <= 3; j++) s += (int64_t)k[j + 3] * rows[(size_t)reflect101(y + j, h) * w + x];
             int64_t q = s >> 16, r = s & 0xFFFF;
             if (r > 32768) q += 1;
-            else if (r == 32768) q += (tie_mode == 1 && x < body) ? (q & 1) : 1;
+            else if (r == 32768) q += (x < body) ? (q & 1) : 1;
             dst[(size_t)y * dstride + x] = (uint8_t)std::min<int64_t>(q, 255);
         }
 }

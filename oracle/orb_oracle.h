@@ -42,8 +42,12 @@ typedef struct {
     int   nlevels;        /* 8     :38 */
     int   fast_threshold; /* 20    :44 */
     /* edgeThreshold 31, firstLevel 0, WTA_K 2, HARRIS_SCORE, patchSize 31 are fixed (:39-43). */
-    int   blur_tie_mode;  /* 1 = OpenCV's SIMD column filter rounding (ties-to-even for columns x < (w & ~3),
-                                 ties-up in the scalar tail); 0 = ties-up everywhere (pure scalar build). */
+    int   blur_tie_mode;  /* Where the column filter's vector body (ties to even) ends and its scalar tail (ties up) begins --
+                             it depends on the SIMD width OpenCV's dispatcher picks for SymmColumnVec_32s8u:
+                             1 = body x < (w & ~3) (loops that go down to 4 lanes: the default here), 2 = x < (w & ~7),
+                             3 = x < (w & ~15), 0 = ties up everywhere (a build without SIMD). */
+    int   level_size_mode;/* 0 = cvRound(dim * (1.0f / scale)) (default: what orb.cpp is restated as here),
+                             1 = cvRound(dim / scale) (SURVEY.md A.1's wording). tools/level_size_sweep.py lists where they differ. */
 } orc_params;
 
 void orc_default_params(orc_params* p);
@@ -51,7 +55,8 @@ void orc_default_params(orc_params* p);
 /* ---- geometry ---------------------------------------------------------------------------------------- */
 /* layerScale[l] = (float)pow((double)scaleFactor, l)                     [orb.cpp getScale]              */
 float orc_layer_scale(const orc_params* p, int level);
-/* level size = (cvRound(cols * (1.f/scale)), cvRound(rows * (1.f/scale)))  [orb.cpp detectAndCompute]    */
+/* level size = (cvRound(cols * (1.f/scale)), cvRound(rows * (1.f/scale)))  [orb.cpp detectAndCompute]; level_size_mode 1:
+ * cvRound(cols / scale)                                                                                  */
 void  orc_level_size(const orc_params* p, int w, int h, int level, int* lw, int* lh);
 /* per-level feature quotas                                               [orb.cpp computeKeyPoints]      */
 void  orc_feature_quotas(const orc_params* p, int* quota /*[nlevels]*/);

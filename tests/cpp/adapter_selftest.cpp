@@ -16,6 +16,7 @@
 #include "aria_hip/HipLoopDetector.hpp"
 #include "aria_hip/HipMatcher.hpp"
 #include "aria_hip/OrbHipExtractor.hpp"
+#include "aria_hip/Shard.hpp"
 #include "aria_orb_hip.h"
 
 using namespace aria;
@@ -90,6 +91,16 @@ static int frontend_mock_test() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "gpu";
     if (mode == "frontend_mock") return frontend_mock_test();
+    if (mode == "shard") {       // the partition rule of euroc_frontend --shards, for tests/test_cpp_adapters.py (no GPU)
+        const std::size_t ns[] = {0, 1, 2, 7, 100, 101, 4096, 32768};
+        for (std::size_t n : ns)
+            for (int g = 1; g <= 8; g++)
+                for (int r = 0; r < g; r++) {
+                    const pipeline::ShardPlan p = pipeline::shardPlan(n, r, g);
+                    std::printf("%zu %d %d %zu %zu %zu\n", n, g, r, p.lo, p.hi, p.first);
+                }
+        return 0;
+    }
     const int W = 640, H = 480;
     std::vector<uint8_t> a((size_t)W * H), b((size_t)W * H);
     aria_synth_frame_pair(1, W, H, a.data(), b.data());

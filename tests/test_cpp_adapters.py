@@ -37,6 +37,23 @@ def test_adapters_fail_loudly_without_gpu(selftest):
     assert "OK nogpu" in out.stdout and "no usable HIP device" in out.stdout
 
 
+def test_shard_partition_equals_the_python_rule(selftest):
+    """aria_hip/Shard.hpp (euroc_frontend --shards) and aria_slam_amd/shard.py (bench.py) cut a sequence the same way:
+    contiguous ranges that cover it once, a one-frame halo in front of every non-empty range but the first."""
+    from aria_slam_amd import shard
+    out = subprocess.run([selftest, "shard"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    rows = [tuple(int(v) for v in l.split()) for l in out.stdout.splitlines()]
+    assert len(rows) == 8 * 36
+    for n, g, r, lo, hi, first in rows:
+        p = shard.shard_plan(n, r, g)
+        assert (lo, hi) == (p["lo"], p["hi"]) and first == p["extract"][0], (n, g, r)
+    for n in (7, 100, 4096):
+        for g in range(1, 9):
+            cover = [i for nn, gg, r, lo, hi, first in rows if nn == n and gg == g for i in range(lo, hi)]
+            assert cover == list(range(n))
+
+
 @pytest.mark.gpu
 def test_adapters_equal_python_binding_and_reference_conventions(aria, selftest):
     out = subprocess.run([selftest, "gpu"], capture_output=True, text=True, timeout=300)

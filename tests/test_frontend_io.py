@@ -235,3 +235,28 @@ def test_euroc_frontend_loop_closure_step(aria, hostlib, oracle, tmp_path):
     assert set(got_loops) == set(want_loops)
     for i in want_loops:
         assert got_loops[i][0] == want_loops[i][0] and abs(got_loops[i][1] - want_loops[i][1]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_euroc_frontend_shards_equal_the_single_shard_run(aria, hostlib, tmp_path):
+    """euroc_frontend --devices N --shards K: K host threads, each with its own extractor + matcher
+    handles over a contiguous frame range with a one-frame halo, results merged in frame order; the loop-closure step
+    consumes the merged stream. Every CSV row (counts, per-frame hash over keypoints + descriptors + matches, keyframe flag,
+    loop id and score) must equal the single-shard run's. One GPU here: the K shards are logical shards on device 0, which
+    also exercises K handles from K host threads at once."""
+    n_pairs, revisit = 230, 6                                      # as in the loop-closure test: the sequence contains a loop
+    seq, _ = _make_dataset(aria, str(tmp_path), n_pairs, w=320, h=240, revisit=revisit)
+    exe = os.path.join(PKG, "euroc_frontend")
+    runs = {}
+    for name, extra in (("one", []), ("k3", ["--devices", "1", "--shards", "3"]), ("k5", ["--shards", "5"])):
+        csv = os.path.join(str(tmp_path), name + ".csv")
+        out = subprocess.run([exe, str(tmp_path), "500", "--csv", csv, "--loop"] + extra, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout + out.stderr
+        runs[name] = open(csv).read().strip().split("\n")
+        if extra:
+            assert "%s shards on 1 device" % extra[-1] in out.stdout
+    assert len(runs["one"]) == len(seq) + 1
+    assert runs["k3"] == runs["one"]
+    assert runs["k5"] == runs["one"]
+    assert sum(int(r.split(",")[5]) for r in runs["one"][1:]) > 50          # keyframes exist, so the loop step did run
+    assert any(int(r.split(",")[6]) >= 0 for r in runs["one"][1:])          # ... and found the loop

@@ -104,3 +104,77 @@ def test_stream_tie_mode_0(aria, oracle, torch_cuda, w, h):
         _check_frames(oracle, imgs, 600, cnt, kps, desc, tie_mode=0)
     finally:
         e.close()
+
+
+# ---- oracle exposure switches: the kernels follow the parameters ------------------------------------
+def _tie_image(aria, w, h, seed):
+    """Upper half: whole columns of exact blur ties (tests/test_oracle_known_answers.py tie_stripes); lower half: a synthetic
+    frame, so that keypoints exist too."""
+    pat = np.array([127, 128, 128, 126, 128, 128, 128], np.uint8)
+    img = aria.synth_frame_pair(seed, w, h)[0].copy()
+    img[: h // 2] = pat[np.arange(w) % 7][None, :]
+    return img
+
+
+@pytest.mark.parametrize("tie_mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("w,h", [(645, 300), (333, 251)])
+def test_blur_tie_modes_follow_the_parameter(aria, oracle, torch_cuda, tie_mode, w, h):
+    """blur_tie_mode 0..3 on an image with many exact ties, through the batch entry point (k_fast_blur_stream) and the
+    single-frame one (k_fast_blur_band): blurred level 0 and the extraction equal the oracle run with the same mode, and the
+    modes really differ on this image."""
+    imgs = np.stack([_tie_image(aria, w, h, 80), _tie_image(aria, w, h, 81)])
+    p = oracle.default_params(400, tie_mode)
+    want_blur = oracle.blur_pyramid(oracle.build_pyramid(imgs[0], p), p, w, h)
+    if tie_mode in (1, 2, 3):
+        other = oracle.default_params(400, 0)
+        assert not np.array_equal(oracle.blur_pyramid(oracle.build_pyramid(imgs[0], other), other, w, h)[0], want_blur[0])
+    e, cnt, kps, desc = _batch(aria, torch_cuda, imgs, 400, tie_mode=tie_mode)
+    try:
+        assert e.fast_blur_kernel() == "k_fast_blur_stream"
+        info = e.level_info(w, h)
+        for l in range(8):
+            got = e.debug_read_level(l, True, info[l][0], info[l][1])
+            assert np.array_equal(got, want_blur[l]), "batch, level %d: %d px differ" % (l, np.count_nonzero(got != want_blur[l]))
+        _check_frames(oracle, imgs, 400, cnt, kps, desc, tie_mode=tie_mode)
+        f = e.extract(imgs[1])                                   # single-frame schedule on the same handle
+        assert e.fast_blur_kernel() == "k_fast_blur_band"
+        ok, od = oracle.orb_extract(imgs[1], p, cap=200000)
+        assert f["keypoints"].tobytes() == ok.tobytes() and np.array_equal(f["descriptors"], od)
+        want1 = oracle.blur_pyramid(oracle.build_pyramid(imgs[1], p), p, w, h)
+        for l in range(8):
+            got = e.debug_read_level(l, True, info[l][0], info[l][1])
+            assert np.array_equal(got, want1[l]), "single frame, level %d" % l
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("w,h", [(558, 300), (640, 117)])
+def test_level_size_mode_follows_the_parameter(aria, oracle, torch_cuda, w, h):
+    """Sizes from profiles/level_size_sweep.txt where cvRound(dim * (1.0f / scale)) != cvRound(dim / scale) (558 at level 2,
+    117 at level 1): with level_size_mode 1 the library's levels and keypoints equal the oracle's in that mode."""
+    imgs = np.stack([aria.synth_frame_pair(90 + i, w, h)[0] for i in range(2)])
+    p0, p1 = oracle.default_params(300, 1, 0), oracle.default_params(300, 1, 1)
+    assert oracle.level_sizes(p0, w, h) != oracle.level_sizes(p1, w, h)
+    n, dev = len(imgs), torch_cuda.device("cuda", 0)
+    s = torch_cuda.cuda.Stream(device=dev)
+    e = aria.OrbHipExtractor(max_features=300, max_width=w, max_height=h, max_batch=n, level_size_mode=1, stream=s.cuda_stream)
+    try:
+        cap = e.kp_capacity()
+        d_img = torch_cuda.from_numpy(imgs).to(dev)
+        kps = torch_cuda.zeros((n, cap, 24), dtype=torch_cuda.uint8, device=dev)
+        desc = torch_cuda.zeros((n, cap, 32), dtype=torch_cuda.uint8, device=dev)
+        cnt = torch_cuda.zeros((n,), dtype=torch_cuda.int32, device=dev)
+        torch_cuda.cuda.synchronize()
+        e.extract_batch_device(d_img, n, w, h, kps, desc, cnt, cap)
+        e.check()
+        c, k, d = cnt.cpu().numpy(), kps.cpu().numpy(), desc.cpu().numpy()
+        for f in range(n):
+            ok, od = oracle.orb_extract(imgs[f], p1)
+            assert c[f] == len(ok) and k[f, :c[f]].tobytes() == ok.tobytes() and np.array_equal(d[f, :c[f]], od)
+        f1 = e.extract(imgs[0])
+        ok, od = oracle.orb_extract(imgs[0], p1)
+        assert f1["keypoints"].tobytes() == ok.tobytes() and np.array_equal(f1["descriptors"], od)
+        ok0, _ = oracle.orb_extract(imgs[0], p0)
+        assert ok0.tobytes() != ok.tobytes()                      # the switch matters at this size
+    finally:
+        e.close()

@@ -1,6 +1,11 @@
-"""Alternative kernel paths (selected by environment variables, read once per process) must give the same bits:
-the 64x32 tile FAST/blur kernel, direct-gather resize, the fused in-LDS pyramid, per-level side streams, the vector-ALU kNN-2, and --
-by shrinking the survivor queue to 1 % -- the dense-rescoring slow path of the band kernel."""
+"""Alternative kernel paths must give the same bits: the band FAST/blur kernel in the batch path (the default there is the
+streaming kernel), the 64x32 tile FAST/blur kernel, the matrix-core blur, direct-gather resize, the fused in-LDS pyramid,
+per-level side streams, the vector-ALU kNN-2, and -- by shrinking the survivor queue to 1 % -- the dense-rescoring slow
+path of the band kernel.
+
+These kernels and the ARIA_* switches that select them are NOT in the product library (libaria_orb_hip.so reads no
+environment variable): this module builds libaria_orb_hip_variants.so (`make -C aria_slam_amd/csrc variants`,
+-DARIA_VARIANTS) itself and points the subprocesses' binding at it through ARIA_ORB_HIP_LIBRARY."""
 import os
 import subprocess
 import sys
@@ -10,8 +15,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+@pytest.fixture(scope="module")
+def variants_lib():
+    sys.path.insert(0, ROOT)
+    import aria_slam_amd
+    return aria_slam_amd.build_variants_library()
+
+
 VARIANTS = [
     {},
+    {"ARIA_FAST_BLUR_IMPL": "band"},                               # batches on the band kernel instead of the streaming one
     {"ARIA_FAST_BLUR_IMPL": "tile"},
     {"ARIA_FAST_BLUR_IMPL": "mfma"},                               # band kernel with the 7x7 blur on the matrix cores (band_mfma.hip)
     {"ARIA_RESIZE_FUSE": "0"},                                     # separate resize pass (dot2 LDS kernel)
@@ -29,22 +42,24 @@ VARIANTS = [
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
-def test_variant_matches_golden(env):
+def test_variant_matches_golden(env, variants_lib):
     e = dict(os.environ)
+    e["ARIA_ORB_HIP_LIBRARY"] = variants_lib
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_check.py")], env=e, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("OK") == 3
+    assert out.stdout.count("OK") == 6
 
 
 @pytest.mark.parametrize("env", [{}, {"ARIA_KNN_NC": "2"}, {"ARIA_KNN_NC": "4"}, {"ARIA_KNN_IMPL": "valu"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
-def test_knn2_kernels_against_brute_force(env):
+def test_knn2_kernels_against_brute_force(env, variants_lib):
     """Matrix-core kNN-2 in both workgroup shapes (256 / 512 queries), both key layouts (train sets above 4096
     descriptors take the 16-bit-index one) and the vector-ALU kernel, through the host, batched-device and
     keyframe-DB entry points, against a numpy brute force."""
     e = dict(os.environ)
+    e["ARIA_ORB_HIP_LIBRARY"] = variants_lib
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_check.py")], env=e, capture_output=True,
                          text=True, timeout=600)

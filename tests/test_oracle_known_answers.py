@@ -252,6 +252,58 @@ def test_gaussian_blur_tie_modes_differ_only_on_exact_ties(oracle):
     assert n_diff >= 1
 
 
+def tie_stripes(h, w):
+    """Image whose 7x7 blur hits EXACT ties in whole columns: rows are identical, period 7 along x with
+    18 a + 34 b + 49 c + 55 d + 49 e + 34 f + 18 g = 32768 at one phase (257 * 32768 = 128.5 * 2^16)."""
+    pat = np.array([127, 128, 128, 126, 128, 128, 128], np.uint8)
+    return np.tile(pat[np.arange(w) % 7][None, :], (h, 1))
+
+
+@pytest.mark.parametrize("w", [61, 645, 652, 655])
+def test_gaussian_blur_vector_tail_modes(oracle, w):
+    """blur_tie_mode 1 / 2 / 3 = vector body of the column filter ends at w & ~3 / w & ~7 / w & ~15: on an
+    image with whole columns of exact ties the modes differ exactly in the tie columns between two body ends."""
+    img = tie_stripes(40, w)
+    s = _blur_sums_numpy(img)
+    q, r = s >> 16, s & 0xFFFF
+    tie = r == 32768
+    assert tie[5:-5].all(axis=0).sum() >= w // 7 - 2              # about one column in seven ties, in every interior row
+    outs = {}
+    for mode, body_end in ((0, 0), (1, w & ~3), (2, w & ~7), (3, w & ~15)):
+        body = (np.arange(w) < body_end)[None, :]
+        want = np.minimum(np.where(tie & body, q + (q & 1), q + (r >= 32768)), 255)
+        outs[mode] = oracle.gaussian_blur7(img, mode)
+        assert np.array_equal(outs[mode], want), mode
+    for a, b, lo, hi in ((1, 2, w & ~7, w & ~3), (2, 3, w & ~15, w & ~7), (0, 1, 0, w & ~3)):
+        diff_cols = np.flatnonzero((outs[a] != outs[b]).any(axis=0))
+        assert all(lo <= c < hi for c in diff_cols)
+        if tie[:, lo:hi].any():
+            assert len(diff_cols) >= 1
+
+
+def test_level_size_modes_and_sweep_file(oracle):
+    """level_size_mode 0 = cvRound(dim * (1.0f / scale)), 1 = cvRound(dim / scale): the oracle follows the switch, and the
+    committed sweep (tools/level_size_sweep.py -> profiles/level_size_sweep.txt) lists exactly where they differ."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "profiles", "level_size_sweep.txt")).read()
+    fresh = subprocess.run([sys.executable, os.path.join(root, "tools", "level_size_sweep.py")], capture_output=True, text=True).stdout
+    assert fresh == txt
+    assert "BASELINE.json sizes affected: none" in txt
+    rows = [tuple(int(v) for v in l.split()) for l in txt.splitlines() if l and not l.startswith("#")]
+    assert len(rows) >= 10
+    p0, p1 = oracle.default_params(1000, 1, 0), oracle.default_params(1000, 1, 1)
+    listed = {(d, l) for d, l, _, _ in rows}
+    for dim, level, a, b in rows[:12] + rows[-12:]:
+        assert oracle.level_sizes(p0, dim, 64 + level)[level][0] == a
+        assert oracle.level_sizes(p1, dim, 64 + level)[level][0] == b
+    for dim in (640, 480, 752, 1408, 333, 251, 100):              # sizes not in the list: both modes agree at every level
+        for level in range(8):
+            assert (dim, level) in listed or oracle.level_sizes(p0, dim, dim)[level] == oracle.level_sizes(p1, dim, dim)[level]
+
+
 def test_gaussian_blur_gain_257_over_256_saturates(oracle):
     assert oracle.gaussian_blur7(np.full((40, 40), 255, np.uint8)).min() == 255
     assert oracle.gaussian_blur7(np.full((40, 40), 100, np.uint8)).tolist()[0][0] == (100 * 257 * 257 + 32768) >> 16

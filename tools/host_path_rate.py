@@ -54,6 +54,51 @@ def main():
     print("aria_orb_extract (host buffers)           : %.1f us/frame = %.0f frames/s" % (1e6 * (t1 - t0) / N1, N1 / (t1 - t0)))
     print("aria_orb_extract + aria_matcher_match     : %.1f us/frame = %.0f frames/s (match calls alone %.1f us, %d..%d keypoints)"
           % (1e6 * (t2 - t1) / N2, N2 / (t2 - t1), 1e6 * tm / N2, min(n[0].value, n[1].value), max(n[0].value, n[1].value)))
+    # device hand-off (getGpuDescriptors / matchGpu): (a) two waits per frame, own streams; (b) the match queued behind
+    # extractAsync on ONE stream, one wait per frame -- with the host time of each of the four calls
+    import torch
+    dev = torch.device("cuda", 0)
+    for shared in (False, True):
+        st = torch.cuda.Stream(device=dev).cuda_stream if shared else None
+        e2 = A.OrbHipExtractor(max_features=NF, max_width=W, max_height=H, stream=st)
+        m2 = A.HipMatcher(stream=st)
+        rc = L.aria_orb_extract(e2._h, seq[0].ctypes.data, W, H, W, kp[1].ctypes.data, ds[1].ctypes.data, cap, C.byref(n[1]))
+        assert rc == 0
+        _, d_desc, d_cnt, n0, rows = e2.device_result()
+        m2.retain_device(d_desc, n0)
+        seg = [0.0] * 4
+        for rep in range(reps // 2 + 1):
+            if rep == 1:
+                t3 = time.perf_counter()
+                seg = [0.0] * 4
+            for i in range(len(seq)):
+                s = i & 1
+                if shared:
+                    a = time.perf_counter()
+                    rc = L.aria_orb_extract_async(e2._h, seq[i].ctypes.data, W, H, W)
+                    b = time.perf_counter()
+                    rc |= L.aria_matcher_match_device_async(m2._h, d_desc, d_cnt, rows, 1, C.c_float(0.75))
+                    c = time.perf_counter()
+                    rc |= L.aria_orb_sync(e2._h, kp[s].ctypes.data, ds[s].ctypes.data, cap, C.byref(n[s]))
+                    d = time.perf_counter()
+                    rc |= L.aria_matcher_finish(m2._h, n[s].value, mt.ctypes.data, cap, C.byref(nm))
+                    f = time.perf_counter()
+                    seg = [seg[0] + b - a, seg[1] + c - b, seg[2] + d - c, seg[3] + f - d]
+                else:
+                    rc = L.aria_orb_extract(e2._h, seq[i].ctypes.data, W, H, W, kp[s].ctypes.data, ds[s].ctypes.data, cap, C.byref(n[s]))
+                    a = time.perf_counter()
+                    rc |= L.aria_matcher_match_device(m2._h, d_desc, n[s].value, None, n[1 - s].value, C.c_float(0.75), mt.ctypes.data, cap, C.byref(nm))
+                    seg[0] += time.perf_counter() - a
+                assert rc == 0, rc
+        t4 = time.perf_counter()
+        if shared:
+            print("extract_async + match_device_async + sync + finish (one stream): %.1f us/frame; calls: extract_async %.1f, "
+                  "match_async %.1f, orb_sync %.1f, finish %.1f us" % (1e6 * (t4 - t3) / N2, *[1e6 * x / N2 for x in seg]))
+        else:
+            print("aria_orb_extract + aria_matcher_match_device (own streams)      : %.1f us/frame (match calls alone %.1f us)"
+                  % (1e6 * (t4 - t3) / N2, 1e6 * seg[0] / N2))
+        e2.close()
+        m2.close()
     # GPU-side stage times of one frame in flight (drained HIP-event brackets: adds host time, so not a rate)
     e.set_profiling(True)
     m.set_profiling(True)

@@ -35,6 +35,25 @@ def main():
         bad += 0 if ok else 1
         e.close()
         m.close()
+        # the same pair through the device-resident batch entry point (its own FAST/blur kernel: the streaming one by default)
+        import torch
+        dev = torch.device("cuda", 0)
+        st = torch.cuda.Stream(device=dev)
+        e = A.OrbHipExtractor(max_features=int(n[1:]), max_width=w, max_height=h, max_batch=2, stream=st.cuda_stream)
+        cap = e.kp_capacity()
+        imgs = torch.from_numpy(np.stack([a, b])).to(dev)
+        kps = torch.zeros((2, cap, 24), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.extract_batch_device(imgs, 2, w, h, kps, desc, cnt, cap)
+        e.check()
+        c, k, d = cnt.cpu().numpy(), kps.cpu().numpy(), desc.cpu().numpy()
+        ok = (sha(k[0, :c[0]]) == g["kp_a"] and sha(d[0, :c[0]]) == g["desc_a"] and sha(k[1, :c[1]]) == g["kp_b"] and
+              sha(d[1, :c[1]]) == g["desc_b"])
+        print(key, "batch (%s)" % e.fast_blur_kernel(), "OK" if ok else "MISMATCH")
+        bad += 0 if ok else 1
+        e.close()
     sys.exit(1 if bad else 0)
 
 
