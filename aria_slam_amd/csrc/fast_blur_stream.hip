@@ -146,13 +146,18 @@ struct StreamArgs {
     int src_pitch, blur_pitch, next_pitch;
     int w, h, next_w, next_h;
     int n_frames, thr, tail_start;
+    // Rows are cut into segments of seg_rows (the last one shorter): a wave walks ONE segment of its panel, with the rows
+    // around it that its first / last output rows need (4 above, 3 below). One segment per level would give the fewest
+    // recomputed rows, but few, long-lived waves: a 1408-row level of 1024 frames is less than one round of waves on 256 CUs
+    // and the last ones run alone. The host picks the segment so that a launch has several rounds (launch_fast_blur_stream).
+    int seg_rows, n_seg, panels;
 };
 
 }  // namespace
 
 template <int WPB, bool TAIL>
 __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __restrict__ wl, const int lane, const LaneRole R,
-                                            const int frame0, unsigned long long* __restrict__ stamps) {
+                                            const int frame0, const int seg, unsigned long long* __restrict__ stamps) {
     // diagnostic builds only (-DARIA_DIAG, ARIA_STREAM_STAMPS=1): s_memtime ticks per phase, summed over the waves of the
     // launch. Not in the product build: the accumulators alone are 16 SGPRs of a kernel that is short of them.
 #ifdef ARIA_DIAG
@@ -164,6 +169,9 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #define PHASE(k) do { } while (0)
 #endif
     const int w = A.w, h = A.h;
+    // this wave's rows: blurred rows, candidates and pyramid source rows [r0, r1); ingest indices t_first .. t_last
+    const int r0 = seg * A.seg_rows, r1 = min(h, r0 + A.seg_rows);
+    const int t_first = r0 == 0 ? -3 : r0 - 4, t_last = r1 == h ? h + 2 : r1 + 3;
     uint32_t* s_raw = reinterpret_cast<uint32_t*>(wl + kHdrBytes);                 // [kRing][64] dwords
     uint8_t* s_rawb = wl + kHdrBytes;
     uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
@@ -188,7 +196,8 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     const uint32_t out_off = (uint32_t)((int64_t)(R.frame - frame0) * A.blur_fstride + 4 * max(R.gdw, 0));
 
     // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); FAST is needed on that region + 1 ring
-    const int fy0 = kEdgeThreshold - 1, fy1 = h - kEdgeThreshold;
+    // ... restricted to the segment + the row above and below it (their scores are the NMS neighbours of its edge rows)
+    const int fy0 = max(kEdgeThreshold - 1, r0 - 1), fy1 = min(h - kEdgeThreshold, r1);
     const int thr = A.thr;
     const uint32_t T2 = (uint32_t)thr * 0x00010001u;
     const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps x-3..x
@@ -231,11 +240,18 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             nout_off = (uint32_t)((int64_t)(R.frame - frame0) * A.next_fstride + 4 * host_gx);
         }
     }
-    int dy_next = 0;                       // next output row of level l+1 (wave-uniform)
+    // next output row of level l+1 (wave-uniform): the first one whose upper source row lies in this segment
+    int dy_next = 0;
+    if (pyr && r0 > 0) {
+        dy_next = min(max((int)(((int64_t)(2 * r0 + 1) * gn_h) / (2 * h)) - 1, 0), gn_h - 1);      // ~ (r0 + 0.5) gn_h / h - 0.5, then exact:
+        while (dy_next > 0 && (int)(yt[dy_next - 1] & 0xFFFFu) >= r0) dy_next--;
+        while (dy_next < gn_h && (int)(yt[dy_next] & 0xFFFFu) < r0) dy_next++;
+        dy_next = __builtin_amdgcn_readfirstlane(dy_next);
+    }
     // the y-table words of 64 output rows at a time, one per lane (a load per row would put an L2 round trip in front of
     // every output row)
-    int yt_base = 0;
-    uint32_t ytv = pyr ? yt[min(lane, gn_h - 1)] : 0u;
+    int yt_base = dy_next;
+    uint32_t ytv = pyr ? yt[min(yt_base + lane, gn_h - 1)] : 0u;
     uint32_t hprev[4] = {0u, 0u, 0u, 0u};
     int hprev_row = -1;
 
@@ -249,7 +265,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     }
 
     auto row_ptr = [&](int t) -> const uint8_t* {                  // level row of ingest index t (REFLECT_101 above / below)
-        const int ry = reflect101(min(t, h + 2), h);
+        const int ry = reflect101(min(max(t, -3), h + 2), h);
         return src0 + (int64_t)ry * pitch_in;
     };
     // Row loads run TWO groups ahead of the walk and are taken out of their registers in the middle of a group (after the
@@ -259,7 +275,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     // group); behind the scoring phase the youngest stores are the blurred rows of the walk, thousands of cycles old.
     uint32_t pre[7], cur[7];
 #pragma unroll
-    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(u - 3) + in_off);
+    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(t_first + u) + in_off);
 #pragma unroll
     for (int u = 0; u < 7; u++) cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
 
@@ -268,7 +284,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 
     int q2n = 0;                 // corners waiting for their lower neighbours' scores (wave-uniform)
     bool dense = false;          // the corner list overflowed once: NMS scans the score ring from here on
-    int nms_done = fy0 - 1;      // rows <= this have been through NMS
+    int nms_done = fy0 - 1;      // rows <= this have been through NMS (diagnostic-free: the dense path starts after it)
 
     // ---- candidates leave through an out-list in LDS, 64 at a time, and the global append is split in two: the slice of
     //      the frame's list is reserved now (one returning atomic per frame in the batch, NOT waited for), the records are
@@ -322,13 +338,13 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         if (all) complete_pending();
     };
 
-    const int G = (h + 6 + 6) / 7;        // ingest indices -3 .. h+2
+    const int G = (t_last - t_first + 1 + 6) / 7;
     // (loads past the last group are issued all the same, clamped to the last row: a condition around them would make the
     // compiler load into temporaries and copy -- i.e. wait -- at once)
 #pragma unroll
-    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(4 + u) + in_off);
+    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(t_first + 7 + u) + in_off);
     for (int gi = 0; gi < G; gi++) {
-        const int t0 = 7 * gi - 3;
+        const int t0 = t_first + 7 * gi;
         // ---- rows of this group into the ring; clear the score rows this group will fill ----
 #pragma unroll
         for (int u = 0; u < 7; u++) {
@@ -345,7 +361,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             const int t = t0 + u;
-            if (t <= h + 2) {
+            if (t <= t_last) {
                 // neighbours' dwords straight from their registers (DPP wave shifts): no LDS round trip in the walk. Lane 0's
                 // left and lane 63's right neighbour do not exist (they read 0): those two lanes only provide pixels.
                 const uint32_t w1 = cur[u];
@@ -368,7 +384,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 // row o+d of the window lives in slot (u + 4 + d) % 7
                 const int sC = (u + 4) % 7, sM1 = (u + 3) % 7, sP1 = (u + 5) % 7, sM2 = (u + 2) % 7, sP2 = (u + 6) % 7,
                           sM3 = (u + 1) % 7, sP3 = u;
-                if (o >= 0 && o < h) {
+                if (o >= r0 && o < r1) {
                     // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u). All values are
                     // integers * 2^-16 below 2^9, so the fp32 column pass is exact (a partial sum can only be inexact above
                     // 256.0, which saturates either way); v_cvt_pk_u8_f32 rounds to nearest EVEN (the SIMD path), saturates
@@ -467,7 +483,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             // (x of the lane's px 0, frame, owner) of the lane that holds the pixel
             const uint32_t li = __builtin_amdgcn_ds_bpermute((px >> 2) << 2, (int)linfo);
             const int X = (int)(li & 0x7FFu) + (px & 3);
-            keep = keep && (li >> 31) && X >= kEdgeThreshold && X < w - kEdgeThreshold && row >= kEdgeThreshold && row < h - kEdgeThreshold;
+            keep = keep && (li >> 31) && X >= kEdgeThreshold && X < w - kEdgeThreshold && row >= max(kEdgeThreshold, r0) && row < min(h - kEdgeThreshold, r1);
             const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
             if (km) {
                 if (outn > kOut - 64) flush_out(false);
@@ -525,14 +541,14 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         //      blends its 4 pixels from the ring (v_perm + v_dot2_u32_u16, the integers of k_resize_lds); the horizontal
         //      blend of the lower source row is kept for the next output row, which starts there 5 times out of 6. ----
         if (pyr) {
-            const int t_last = min(t0 + 6, h - 1);                     // last level row in the ring
+            const int ring_last = min(t0 + 6, min(t_last, h - 1));    // last level row in the ring
             constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
             while (dy_next < gn_h && dy_next < yt_base + 64) {
                 dy_next = __builtin_amdgcn_readfirstlane(dy_next);
                 const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)ytv, dy_next - yt_base);
                 const int oy = (int)(ty & 0xFFFFu);
                 const int rb = min(oy + 1, h - 1);
-                if (rb > t_last) break;
+                if (rb > ring_last || oy >= r1) break;
                 if (host_gx >= 0) {
                     const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
                     const uint8_t* rowa = s_rawb + ring_off(oy);
@@ -592,9 +608,10 @@ __global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(StreamArgs A, uns
     const int w = A.w, h = A.h;
     const int D = (w + 3) >> 2, U = D + 2;
     const int wave_id = (int)blockIdx.x * WPB + wv;
+    const int seg = wave_id / A.panels, pw = wave_id - seg * A.panels;      // segment-major: a workgroup's waves are neighbours in x
+    if (seg >= A.n_seg) return;                          // no barrier anywhere in this kernel: a wave may leave
     const int64_t total = (int64_t)A.n_frames * U;
-    const int64_t pos0 = (int64_t)wave_id * kOwned - 1;
-    if (pos0 + 1 >= total) return;                       // no barrier anywhere in this kernel: a wave may leave
+    const int64_t pos0 = (int64_t)pw * kOwned - 1;
     int64_t pos = pos0 + lane;
     const bool valid = pos >= 0 && pos < total;
     pos = min(max(pos, (int64_t)0), total - 1);
@@ -628,8 +645,8 @@ __global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(StreamArgs A, uns
     }
     uint8_t* wl = smem + wv * kWaveLds;
     const bool any_tail = __builtin_amdgcn_ballot_w64(R.tailbits != 0) != 0;
-    if (any_tail) stream_wave<WPB, true>(A, wl, lane, R, frame0, stamps);
-    else stream_wave<WPB, false>(A, wl, lane, R, frame0, stamps);
+    if (any_tail) stream_wave<WPB, true>(A, wl, lane, R, frame0, seg, stamps);
+    else stream_wave<WPB, false>(A, wl, lane, R, frame0, seg, stamps);
 }
 
 // The batch path takes this kernel when every level is at least 16 px wide and high (tiny images stay with the band
@@ -670,14 +687,25 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
     static unsigned long long* d_stamps = nullptr;
     if (want_stamps && !d_stamps) hipMalloc(&d_stamps, 8 * sizeof(unsigned long long));
     (void)ctx;
-    static const int wpb = [] { const char* e = aria_getenv("ARIA_STREAM_WPB"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+    static const int seg_force = [] { const char* e = aria_getenv("ARIA_STREAM_SEG_ROWS"); return e ? atoi(e) : 0; }();    // variants build
+    static const int wpb = [] { const char* e = aria_getenv("ARIA_STREAM_WPB"); const int v = e ? atoi(e) : 1; return (v == 2 || v == 4) ? v : 1; }();     // one wave per workgroup:
+    // the waves share nothing, and single-wave workgroups fill the gaps the matcher's workgroups leave (293.6k frames/s
+    // against 288.7k with four waves per workgroup)
     for (int l = 0; l < kLevels; l++) {
         const LevelGeom& g = P.lv[l];
         const int U = ((g.w + 3) >> 2) + 2;
         const int64_t total = (int64_t)n_frames * U;
-        const int64_t waves = (total + kOwned - 1) / kOwned;         // wave k owns virtual dwords 62 k .. 62 k + 61
+        const int64_t panels = (total + kOwned - 1) / kOwned;        // panel k owns virtual dwords 62 k .. 62 k + 61
+        // row segments: enough waves for ~6 rounds on the chip (256 CUs x 12 waves), none shorter than 64 rows (each
+        // segment re-ingests 7 rows of its neighbours)
+        int n_seg = (int)std::min<int64_t>(std::max<int64_t>((6 * 256 * 12 + panels - 1) / panels, 1), std::max(g.h / 64, 1));
+        if (seg_force > 0) n_seg = std::min(std::max(g.h / seg_force, 1), 64);
+        const int seg_rows = (g.h + n_seg - 1) / n_seg;
+        n_seg = (g.h + seg_rows - 1) / seg_rows;
+        const int64_t waves = panels * n_seg;
         const dim3 grid((unsigned)((waves + wpb - 1) / wpb));
         StreamArgs A{};
+        A.seg_rows = seg_rows; A.n_seg = n_seg; A.panels = (int)panels;
         if (l == 0) { A.src = S.img; A.src_fstride = S.frame_stride; A.src_pitch = S.row_stride; }
         else { A.src = D.raw + g.raw_off; A.src_fstride = P.raw_frame_bytes; A.src_pitch = g.pitch; }
         A.blur = D.blur + g.blur_off; A.blur_fstride = P.blur_frame_bytes; A.blur_pitch = g.pitch;
@@ -689,7 +717,9 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
             A.next = D.raw + gn.raw_off; A.next_fstride = P.raw_frame_bytes; A.next_pitch = gn.pitch; A.next_w = gn.w; A.next_h = gn.h;
             A.xt = D.tab + gn.xtab; A.yt = D.tab + gn.ytab; A.xinv = D.tab + gn.xinv;
         }
-#define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), (size_t)N * kWaveLds, st, A, d_stamps)
+        // (variants build: ARIA_STREAM_LDS_KB pads the workgroup's LDS to lower the occupancy -- how the kernel scales with waves per SIMD)
+        static const size_t lds_pad = [] { const char* e = aria_getenv("ARIA_STREAM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+#define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), std::max((size_t)N * kWaveLds, lds_pad), st, A, d_stamps)
         if (d_stamps) hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), st);
         if (wpb == 1) ARIA_FS_LAUNCH(1); else if (wpb == 2) ARIA_FS_LAUNCH(2); else ARIA_FS_LAUNCH(4);
 #undef ARIA_FS_LAUNCH

@@ -458,7 +458,27 @@ def main():
     seed0 = 1 + lo_frame // 2
     host = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=False)
     A.synth_sequence(seed0, args.pairs, W, H, out=host.numpy())
+    # H2D staging of the shard, reported separately and never part of `value`: the upload from
+    # pageable memory as a sequence reader would hold it, and once more from pinned memory (what a reader that decodes
+    # into registered buffers gets). Scaling is linear in the GPUs as long as these rates exceed the compute rate.
+    torch.cuda.synchronize(dev)
+    t_up = time.perf_counter()
     images = host.to(dev)
+    torch.cuda.synchronize(dev)
+    t_up = time.perf_counter() - t_up
+    staging = {"bytes": int(host.numel()), "pageable_s": round(t_up, 4), "pageable_GBs": round(host.numel() / t_up / 1e9, 2)}
+    try:
+        n_pin = min(B, 2048)
+        pinned = host[:n_pin].pin_memory()
+        torch.cuda.synchronize(dev)
+        t_pin = time.perf_counter()
+        images[:n_pin].copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        t_pin = time.perf_counter() - t_pin
+        staging.update({"pinned_sample_bytes": int(pinned.numel()), "pinned_GBs": round(pinned.numel() / t_pin / 1e9, 2)})
+        del pinned
+    except RuntimeError as ex:          # pinning can be refused (memory limits): the pageable figure stands alone
+        staging["pinned_error"] = str(ex)[:120]
     # halo frame (shard.shard_plan: the frame before this rank's range, recomputed rather than exchanged); rank 0 has
     # no predecessor and wraps around to its own last frame
     if rank > 0:
@@ -765,6 +785,10 @@ def main():
             out["loop_closure"] = loop_closure
         if single is not None:
             out["single_frame_host_path"] = single
+        staging["frames_per_s_at_pageable_rate"] = round(staging["pageable_GBs"] * 1e9 / (W * H), 1)
+        staging["note"] = ("upload of this rank's %d frames before the timed region; not part of `value`. The extractor "
+                           "consumes %.1f GB/s of frames at the measured rate" % (B, out["value"] / max(n_gpus, 1) * W * H / 1e9))
+        out["h2d_staging"] = staging
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, NF, args.cpu_budget)
         print(json.dumps(out), flush=True)
