@@ -150,7 +150,7 @@ struct StreamArgs {
     // around it that its first / last output rows need (4 above, 3 below). One segment per level would give the fewest
     // recomputed rows, but few, long-lived waves: a 1408-row level of 1024 frames is less than one round of waves on 256 CUs
     // and the last ones run alone. The host picks the segment so that a launch has several rounds (launch_fast_blur_stream).
-    int seg_rows, n_seg, panels;
+    int seg_rows, n_seg, panels, panels8;
 };
 
 }  // namespace
@@ -265,7 +265,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     }
 
     auto row_ptr = [&](int t) -> const uint8_t* {                  // level row of ingest index t (REFLECT_101 above / below)
-        const int ry = reflect101(min(max(t, -3), h + 2), h);
+        const int ry = reflect101(min(max(t, -3), t_last), h);      // (the loads issued past the segment's end repeat its last row: cache hits)
         return src0 + (int64_t)ry * pitch_in;
     };
     // Row loads run TWO groups ahead of the walk and are taken out of their registers in the middle of a group (after the
@@ -608,8 +608,14 @@ __global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(StreamArgs A, uns
     const int w = A.w, h = A.h;
     const int D = (w + 3) >> 2, U = D + 2;
     const int wave_id = (int)blockIdx.x * WPB + wv;
-    const int seg = wave_id / A.panels, pw = wave_id - seg * A.panels;      // segment-major: a workgroup's waves are neighbours in x
-    if (seg >= A.n_seg) return;                          // no barrier anywhere in this kernel: a wave may leave
+    // Workgroups go round-robin to the 8 XCDs (each with its own L2) by linear id. Neighbouring panels share the 128-byte
+    // lines their 248-byte row pieces end in (rows are not cut at line boundaries), so XCD k is given a CONTIGUOUS eighth of
+    // the panels: the shared lines are then fetched, and the partial lines written, by one L2 (before: 1.7x the level bytes
+    // fetched and 1.2x written, FETCH_SIZE / WRITE_SIZE). A.panels8 = ceil(panels / 8).
+    const int per_seg = 8 * A.panels8;
+    const int seg = wave_id / per_seg, rr = wave_id - seg * per_seg;
+    const int pw = (rr & 7) * A.panels8 + (rr >> 3);
+    if (seg >= A.n_seg || pw >= A.panels) return;        // no barrier anywhere in this kernel: a wave may leave
     const int64_t total = (int64_t)A.n_frames * U;
     const int64_t pos0 = (int64_t)pw * kOwned - 1;
     int64_t pos = pos0 + lane;
@@ -702,10 +708,11 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
         if (seg_force > 0) n_seg = std::min(std::max(g.h / seg_force, 1), 64);
         const int seg_rows = (g.h + n_seg - 1) / n_seg;
         n_seg = (g.h + seg_rows - 1) / seg_rows;
-        const int64_t waves = panels * n_seg;
+        const int64_t panels8 = (panels + 7) / 8;
+        const int64_t waves = 8 * panels8 * n_seg;
         const dim3 grid((unsigned)((waves + wpb - 1) / wpb));
         StreamArgs A{};
-        A.seg_rows = seg_rows; A.n_seg = n_seg; A.panels = (int)panels;
+        A.seg_rows = seg_rows; A.n_seg = n_seg; A.panels = (int)panels; A.panels8 = (int)panels8;
         if (l == 0) { A.src = S.img; A.src_fstride = S.frame_stride; A.src_pitch = S.row_stride; }
         else { A.src = D.raw + g.raw_off; A.src_fstride = P.raw_frame_bytes; A.src_pitch = g.pitch; }
         A.blur = D.blur + g.blur_off; A.blur_fstride = P.blur_frame_bytes; A.blur_pitch = g.pitch;

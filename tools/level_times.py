@@ -47,15 +47,15 @@ def main():
     ev = []
     for name, gx, gy, wg, t0, t1 in launches(path):
         if "k_fast_blur_stream" in name:
-            U = (dims[0][0] + 3) // 4 + 2
-            if gx // max(wg, 1) * (wg // 64) * 62 >= B * U // 2 or True:
-                ev.append((name, gx, gy, wg, t0, t1))
+            ev.append((name, gx, gy, wg, t0, t1))
         elif "k_fast_blur_band" in name and gy == B:
             ev.append((name, gx, gy, wg, t0, t1))
-    # passes = runs of 8 launches whose grids shrink level by level
+    # passes = runs of 8 consecutive launches (level order). The streaming kernel is launched by batches only; the band
+    # kernel's batch launches were selected by their grid (frames in y)
     passes = [ev[i:i + 8] for i in range(0, len(ev) - len(ev) % 8, 8)]
-    passes = [p for p in passes if all(p[k][1] * p[k][2] >= p[k + 1][1] * p[k + 1][2] for k in range(7))
-              and p[0][1] // max(p[0][3], 1) * (p[0][3] // 64) * 62 * (1 if "stream" in p[0][0] else 10 ** 9) >= B * ((dims[0][0] + 3) // 4 + 2) * 0.9]
+    if passes and "stream" in passes[0][0][0]:
+        U0 = (dims[0][0] + 3) // 4 + 2
+        passes = [p for p in passes if (p[0][1] // 64) * 62 >= B * U0 * 0.9 and (p[0][1] // 64) * 62 < B * U0 * 40]
     if not passes:
         print("no batch FAST/blur passes of %d frames found" % B)
         return 1

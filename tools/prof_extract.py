@@ -46,6 +46,15 @@ def main():
         dst = torch.empty_like(src)
         torch.cuda.synchronize()
         dst.copy_(src)
+        # the same gigabyte once more with ONE DWORD per lane (k_fast_blur_stream's row loads): tools/microbench/copy_dword.hip,
+        # built by tools/pmc_traffic.sh next to this script's output
+        so = os.environ.get("ARIA_CALIB_COPY_SO")
+        if so and os.path.exists(so):
+            import ctypes
+            lib = ctypes.CDLL(so)
+            lib.calib_copy_dword.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            torch.cuda.synchronize()
+            assert lib.calib_copy_dword(src.data_ptr(), dst.data_ptr(), src.numel(), stream) == 0
     torch.cuda.synchronize()
     ext.check()
     mat.sync()
