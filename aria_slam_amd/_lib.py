@@ -36,7 +36,7 @@ EXPORTS = [
     "aria_kfdb_add", "aria_kfdb_add_device", "aria_kfdb_info", "aria_kfdb_fetch", "aria_kfdb_scan",
     "aria_orb_last_device", "aria_matcher_match_device", "aria_matcher_retain_device", "aria_matcher_resident_rows",
     "aria_matcher_match_device_async", "aria_matcher_finish", "aria_kfdb_match", "aria_stream_create", "aria_stream_destroy",
-    "aria_orb_fast_blur_kernel",
+    "aria_orb_fast_blur_kernel", "aria_flag_keypoints_shifted_device",
 ]
 
 
@@ -166,6 +166,8 @@ def load_library():
                                                C.c_int64, C.c_double, C.c_void_p]
     L.aria_flag_keypoints_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.c_void_p]
+    L.aria_flag_keypoints_shifted_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.aria_matcher_match_batch_filtered_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                            C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                            C.c_void_p, C.c_int, C.c_void_p]

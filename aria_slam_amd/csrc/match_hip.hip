@@ -232,18 +232,24 @@ __global__ __launch_bounds__(NT) void k_ratio_compact(const uint2* __restrict__ 
 // src/main.cpp:42-50 isInDynamicObject for every keypoint of every frame: flags[f][i] = 1 when keypoint i lies in one of
 // frame f's boxes (x1, y1, x2, y2). mode 0: cv::Rect::contains of the point rounded to integers (half to even), half-open;
 // mode 1: core::Detection::contains (include/core/Types.hpp:109-111), closed float intervals.
+// box_frame_offset: frame f's keypoints are tested against the boxes of frame f + offset (no boxes where that frame does not
+// exist): offset 0 for the query side, +1 for the TRAIN side of pairs (f + 1, f) -- main.cpp tests both endpoints of a match
+// against the CURRENT frame's detections.
 __global__ __launch_bounds__(256) void k_flag_keypoints(const aria_keypoint* __restrict__ kps, const int* __restrict__ counts,
                                                         int kp_cap, const float4* __restrict__ boxes, const int* __restrict__ nboxes,
-                                                        int box_cap, int mode, uint8_t* __restrict__ flags) {
+                                                        int box_cap, int mode, uint8_t* __restrict__ flags, int box_frame_offset,
+                                                        int n_frames) {
     __shared__ float4 s_box[64];
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const int nb = min(nboxes[f], box_cap), n = min(counts[f], kp_cap);
+    const int fb = f + box_frame_offset;
+    const bool has_boxes = fb >= 0 && fb < n_frames;
+    const int nb = has_boxes ? min(nboxes[fb], box_cap) : 0, n = min(counts[f], kp_cap);
     bool hit = false;
     float x = 0.f, y = 0.f;
     if (i < n) { x = kps[(int64_t)f * kp_cap + i].x; y = kps[(int64_t)f * kp_cap + i].y; }
     for (int b0 = 0; b0 < nb; b0 += 64) {
         __syncthreads();
-        if (threadIdx.x < 64 && b0 + (int)threadIdx.x < nb) s_box[threadIdx.x] = boxes[(int64_t)f * box_cap + b0 + threadIdx.x];
+        if (threadIdx.x < 64 && b0 + (int)threadIdx.x < nb) s_box[threadIdx.x] = boxes[(int64_t)fb * box_cap + b0 + threadIdx.x];
         __syncthreads();
         for (int b = 0; b < min(64, nb - b0); b++) {
             const float4 r = s_box[b];
@@ -831,15 +837,22 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
     return ARIA_OK;
 }
 
-int aria_flag_keypoints_device(void* stream, const aria_keypoint* d_kps, const int* d_counts, int n_frames, int kp_cap,
-                               const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, uint8_t* d_flags) {
+int aria_flag_keypoints_shifted_device(void* stream, const aria_keypoint* d_kps, const int* d_counts, int n_frames, int kp_cap,
+                                       const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, int box_frame_offset,
+                                       uint8_t* d_flags) {
     if (!d_kps || !d_counts || !d_boxes || !d_nboxes || !d_flags || n_frames < 0 || kp_cap < 1 || box_cap < 1 || (mode != 0 && mode != 1))
         return ARIA_E_INVALID;
     if (n_frames == 0) return ARIA_OK;
     hipLaunchKernelGGL(k_flag_keypoints, dim3((unsigned)((kp_cap + 255) / 256), (unsigned)n_frames), dim3(256), 0, (hipStream_t)stream,
-                       d_kps, d_counts, kp_cap, reinterpret_cast<const float4*>(d_boxes), d_nboxes, box_cap, mode, d_flags);
+                       d_kps, d_counts, kp_cap, reinterpret_cast<const float4*>(d_boxes), d_nboxes, box_cap, mode, d_flags,
+                       box_frame_offset, n_frames);
     ARIA_HIP(hipGetLastError());
     return ARIA_OK;
+}
+
+int aria_flag_keypoints_device(void* stream, const aria_keypoint* d_kps, const int* d_counts, int n_frames, int kp_cap,
+                               const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, uint8_t* d_flags) {
+    return aria_flag_keypoints_shifted_device(stream, d_kps, d_counts, n_frames, kp_cap, d_boxes, d_nboxes, box_cap, mode, 0, d_flags);
 }
 
 int aria_matcher_match_batch_filtered_device(aria_matcher_t m, const uint8_t* d_query, const int* d_nq, const uint8_t* d_train,

@@ -329,8 +329,12 @@ class HipMatcher:
         return self._L.aria_matcher_stream(self._h)
 
 
-def flag_keypoints_device(stream, d_keypoints, d_counts, n_frames, kp_cap, d_boxes, d_nboxes, box_cap, mode, d_flags):
-    """main.cpp:42-50 for every keypoint of every frame (boxes are an input; mode 0 legacy cv::Rect test, 1 Detection::contains)."""
+def flag_keypoints_device(stream, d_keypoints, d_counts, n_frames, kp_cap, d_boxes, d_nboxes, box_cap, mode, d_flags,
+                          box_frame_offset=0):
+    """main.cpp:42-50 for every keypoint of every frame (boxes are an input; mode 0 legacy cv::Rect test, 1 Detection::contains).
+    box_frame_offset = +1: frame f's keypoints against frame f + 1's boxes (the train flags of pair (f + 1, f) in the
+    reference's semantics, main.cpp:164-175)."""
     L = _lib.load_library()
-    check(L.aria_flag_keypoints_device(stream, _ptr(d_keypoints), _ptr(d_counts), n_frames, kp_cap, _ptr(d_boxes),
-                                       _ptr(d_nboxes), box_cap, mode, _ptr(d_flags)), "aria_flag_keypoints_device")
+    check(L.aria_flag_keypoints_shifted_device(stream, _ptr(d_keypoints), _ptr(d_counts), n_frames, kp_cap, _ptr(d_boxes),
+                                               _ptr(d_nboxes), box_cap, mode, box_frame_offset, _ptr(d_flags)),
+          "aria_flag_keypoints_shifted_device")

@@ -267,6 +267,18 @@ int aria_matcher_match_batch_device(aria_matcher_t m, const uint8_t* d_query, co
 typedef struct { float x1, y1, x2, y2; } aria_box;
 int aria_flag_keypoints_device(void* stream, const aria_keypoint* d_keypoints, const int* d_counts, int n_frames, int kp_cap,
                                const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, uint8_t* d_flags);
+/* The reference's semantics for pairs of consecutive frames. main.cpp:164-175 tests BOTH endpoints of a match against the
+ * detections of the CURRENT frame, so the train side of pair (f + 1, f) -- frame f's keypoints -- must be flagged against
+ * frame f + 1's boxes, not its own (which is what the call above gives when one flag array serves as query flags of one pair
+ * and train flags of the next). box_frame_offset = +1 produces exactly those train flags into a second array (frames whose
+ * f + offset does not exist get no flag); offset 0 is the call above. Batched use with the reference's semantics:
+ *   aria_flag_keypoints_device(...,          d_qflags);          // query flags: frame f vs boxes f
+ *   aria_flag_keypoints_shifted_device(..., +1, d_tflags);       // train flags: frame f vs boxes f + 1
+ *   aria_matcher_match_batch_filtered_device(m, desc + stride, cnt + 1, desc, cnt, B - 1, stride, ratio,
+ *                                            d_qflags + kp_cap, d_tflags, kp_cap, ...);   // pair p: query f = p + 1, train f = p */
+int aria_flag_keypoints_shifted_device(void* stream, const aria_keypoint* d_keypoints, const int* d_counts, int n_frames, int kp_cap,
+                                       const aria_box* d_boxes, const int* d_nboxes, int box_cap, int mode, int box_frame_offset,
+                                       uint8_t* d_flags);
 int aria_matcher_match_batch_filtered_device(aria_matcher_t m, const uint8_t* d_query, const int* d_nq, const uint8_t* d_train,
                                              const int* d_nt, int n_pairs, int64_t desc_stride, float ratio,
                                              const uint8_t* d_qflags, const uint8_t* d_tflags, int64_t flag_stride,

@@ -749,6 +749,25 @@ def test_dynamic_object_filter_on_device_equals_oracle(aria, oracle, torch_cuda,
         want, wf = oracle.filter_dynamic_matches(kq, kt, all_m, boxes[f, :nbox[f]], mode)
         got_n, got_f = int(nm.cpu()[0]), int(nfl.cpu()[0])
         assert got_n == len(want) and got_f == wf and matches.cpu().numpy()[0, :got_n].tobytes() == want.tobytes()
+        # the reference's semantics for the whole batch in ONE call: train flags = frame f's keypoints against frame
+        # f + 1's boxes (box_frame_offset +1), query flags = frame f against its own; every pair equals the oracle's
+        # restatement of main.cpp:164-175 with the current frame's detection list for both endpoints
+        with torch.cuda.stream(s):
+            tflags = torch.full((B, cap), 9, dtype=torch.uint8, device=dev)
+            aria.flag_keypoints_device(s.cuda_stream, kps, cnt, B, cap, d_boxes, d_nbox, box_cap, mode, flags)
+            aria.flag_keypoints_device(s.cuda_stream, kps, cnt, B, cap, d_boxes, d_nbox, box_cap, mode, tflags, box_frame_offset=1)
+            m.match_batch_filtered_device(desc.data_ptr() + cap * 32, cnt.data_ptr() + 4, desc, cnt, B - 1, cap * 32, 0.75,
+                                          flags.data_ptr() + cap, tflags, cap, matches.data_ptr() + cap * 12, nm.data_ptr() + 4,
+                                          cap, nfl.data_ptr() + 4)
+        m.sync()
+        mt_h, nm_h, nfl_h = matches.cpu().numpy(), nm.cpu().numpy(), nfl.cpu().numpy()
+        assert tflags.cpu().numpy()[B - 1].max() == 0                               # no frame B: no boxes, no flags
+        for f in range(1, B):
+            kq = kps_h[f, :cnt_h[f]].copy().view(oracle.KP_DTYPE).reshape(-1)
+            kt = kps_h[f - 1, :cnt_h[f - 1]].copy().view(oracle.KP_DTYPE).reshape(-1)
+            all_m = oracle.match_ratio(desc_h[f, :cnt_h[f]], desc_h[f - 1, :cnt_h[f - 1]], 0.75)
+            want, wf = oracle.filter_dynamic_matches(kq, kt, all_m, boxes[f, :nbox[f]], mode)
+            assert nm_h[f] == len(want) and nfl_h[f] == wf and mt_h[f, :nm_h[f]].tobytes() == want.tobytes(), f
     finally:
         e.close()
         m.close()
