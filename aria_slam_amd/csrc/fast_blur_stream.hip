@@ -53,6 +53,27 @@ constexpr int kOwned = 62;                        // productive lanes per wave (
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Global accesses as "wave-uniform 64-bit base in SGPRs + the lane's 32-bit offset" (global_load/store v_off, s[base]).
+// Left alone the compiler folds the lane's constant offset into a 64-bit VGPR base and pays a v_mad_i64_i32 (and a VGPR
+// pair) per row load and store; the empty asm pins the row base to the scalar unit (243 -> 69 of them in the object; the
+// Q4 build 1.739 -> 1.703 us per frame), the address space keeps the access global (an integer turned pointer would be a
+// FLAT access, which also counts on lgkmcnt).
+template <typename T>
+__device__ __forceinline__ T gload_sv(const uint8_t* base, uint32_t off) {
+    uint64_t b = reinterpret_cast<uint64_t>(base);
+    asm volatile("" : "+s"(b));
+    typedef const T __attribute__((address_space(1))) * gp;
+    return *reinterpret_cast<gp>(b + off);
+}
+template <typename T>
+__device__ __forceinline__ void gstore_sv(uint8_t* base, uint32_t off, T v) {
+    uint64_t b = reinterpret_cast<uint64_t>(base);
+    asm volatile("" : "+s"(b));
+    typedef T __attribute__((address_space(1))) * gp;
+    *reinterpret_cast<gp>(b + off) = v;
+}
 
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
@@ -97,12 +118,17 @@ __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int 
     const uint8_t* rp1 = ring + ring_off(row + 1) + px; const uint8_t* rp2 = ring + ring_off(row + 2) + px;
     const uint8_t* rp3 = ring + ring_off(row + 3) + px;
     const uint32_t v = c[0];
-    const uint32_t vhi = v << 16;
     uint32_t rg[16] = {rp3[0], rp3[1], rp2[2], rp1[3], c[3], rm1[3], rm2[2], rm3[1],
                        rm3[0], rm3[-1], rm2[-2], rm1[-3], c[-3], rp1[-3], rp2[-2], rp3[-1]};
     uint32_t Pk[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) Pk[k] = pk_sub_i16(v | (rg[k] << 16), rg[k] | vhi);
+    for (int k = 0; k < 16; k++) {
+        // (v - ring, ring - v) from ONE packed register (v | ring << 16) and itself with the halves swapped (op_sel of the
+        // packed subtract): one operand to build instead of two
+        // (the compiler does not fold the swizzle into op_sel: it builds the swapped operand with a v_perm)
+        const uint32_t x = v | (rg[k] << 16);
+        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(Pk[k]) : "v"(x));
+    }
     uint32_t M2[16], M4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) M2[k] = pk_min_i16(Pk[k], Pk[(k + 1) & 15]);
@@ -193,7 +219,8 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     else xload = 4 * R.gdw;
     const uint32_t in_off = (uint32_t)((int64_t)(R.frame - frame0) * fstride_in + xload);
     uint8_t* blur0 = A.blur + (int64_t)frame0 * A.blur_fstride;
-    const uint32_t out_off = (uint32_t)((int64_t)(R.frame - frame0) * A.blur_fstride + 4 * max(R.gdw, 0));
+    // the blurred level is stored in Q4 order (orb_device.h): dword column gdw of row o at (o >> 2) * 4 * pitch + 16 gdw + 4 (o & 3)
+    const uint32_t out_off = (uint32_t)((int64_t)(R.frame - frame0) * A.blur_fstride + 16 * max(R.gdw, 0));
 
     // keypoints.cpp runByImageBorder keeps x in [31, w-31), y in [31, h-31); FAST is needed on that region + 1 ring
     // ... restricted to the segment + the row above and below it (their scores are the NMS neighbours of its edge rows)
@@ -275,13 +302,14 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     // group); behind the scoring phase the youngest stores are the blurred rows of the walk, thousands of cycles old.
     uint32_t pre[7], cur[7];
 #pragma unroll
-    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(t_first + u) + in_off);
+    for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t_first + u), in_off);
 #pragma unroll
     for (int u = 0; u < 7; u++) cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
 
     // per-lane info for whoever processes a queue entry of this lane's pixels: x of px 0 | frame - frame0 | owner
     const uint32_t linfo = (uint32_t)(4 * max(R.gdw, 0)) | ((uint32_t)(R.frame - frame0) << 11) | (R.owner ? 1u << 31 : 0u);
 
+    const uint32_t lane_hi = (uint32_t)lane << 8;      // queue entry of a survivor: lane << 8 | bit of accw  (>> 6 = 4 * lane)
     int q2n = 0;                 // corners waiting for their lower neighbours' scores (wave-uniform)
     bool dense = false;          // the corner list overflowed once: NMS scans the score ring from here on
     int nms_done = fy0 - 1;      // rows <= this have been through NMS (diagnostic-free: the dense path starts after it)
@@ -342,7 +370,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     // (loads past the last group are issued all the same, clamped to the last row: a condition around them would make the
     // compiler load into temporaries and copy -- i.e. wait -- at once)
 #pragma unroll
-    for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(t_first + 7 + u) + in_off);
+    for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t_first + 7 + u), in_off);
     for (int gi = 0; gi < G; gi++) {
         const int t0 = t_first + 7 * gi;
         // ---- rows of this group into the ring; clear the score rows this group will fill ----
@@ -392,16 +420,35 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                     // floor(x) = x - fract(x), an integer, which the same conversion leaves alone.
                     constexpr float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
                     uint32_t outw = 0;
+                    typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        float acc = TAIL ? __builtin_fmaf(k0, RF[sC][j], tb[j]) : k0 * RF[sC][j];
-                        acc = __builtin_fmaf(k1, RF[sM1][j] + RF[sP1][j], acc);
-                        acc = __builtin_fmaf(k2, RF[sM2][j] + RF[sP2][j], acc);
-                        acc = __builtin_fmaf(k3, RF[sM3][j] + RF[sP3][j], acc);
-                        if (TAIL) acc = __builtin_fmaf(-__builtin_amdgcn_fractf(acc), tm[j], acc);
-                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc, j, outw);
+                    for (int p = 0; p < 2; p++) {          // two pixels per v_pk_add_f32
+                        const int j = 2 * p;
+                        const f2 c = {RF[sC][j], RF[sC][j + 1]};
+                        const f2 s1 = f2{RF[sM1][j], RF[sM1][j + 1]} + f2{RF[sP1][j], RF[sP1][j + 1]};
+                        const f2 s2 = f2{RF[sM2][j], RF[sM2][j + 1]} + f2{RF[sP2][j], RF[sP2][j + 1]};
+                        const f2 s3 = f2{RF[sM3][j], RF[sM3][j + 1]} + f2{RF[sP3][j], RF[sP3][j + 1]};
+                        // (v_pk_fma_f32 for these: 8 SGPRs of constants, no faster -- 1.704 against 1.700 us per frame)
+                        f2 acc;
+                        acc.x = TAIL ? __builtin_fmaf(k0, c.x, tb[j]) : k0 * c.x;
+                        acc.y = TAIL ? __builtin_fmaf(k0, c.y, tb[j + 1]) : k0 * c.y;
+                        acc.x = __builtin_fmaf(k1, s1.x, acc.x); acc.y = __builtin_fmaf(k1, s1.y, acc.y);
+                        acc.x = __builtin_fmaf(k2, s2.x, acc.x); acc.y = __builtin_fmaf(k2, s2.y, acc.y);
+                        acc.x = __builtin_fmaf(k3, s3.x, acc.x); acc.y = __builtin_fmaf(k3, s3.y, acc.y);
+                        if (TAIL) {
+                            acc.x = __builtin_fmaf(-__builtin_amdgcn_fractf(acc.x), tm[j], acc.x);
+                            acc.y = __builtin_fmaf(-__builtin_amdgcn_fractf(acc.y), tm[j + 1], acc.y);
+                        }
+                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, j, outw);
+                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, j + 1, outw);
                     }
-                    if (R.owner) { uint8_t* orow = blur0 + (int64_t)o * A.blur_pitch; *reinterpret_cast<uint32_t*>(orow + out_off) = outw; }
+                    // Q4 order (orb_device.h): dword column gdw of row o at (o >> 2) * 4 * pitch + 16 gdw + 4 (o & 3). What the
+                    // layout costs HERE (640x480, 8192 frames, rocprofv3, one box): row-major 1.626 us per frame, Q4 1.703
+                    // (levels 0-2 +9 / +6 / +6 %, levels 5-7 < 2 %; HBM bytes written +4.7 %, fetched the same) -- against
+                    // 0.127 us less in k_describe. Collecting the four rows of a quad in registers for one 16-byte store
+                    // needs a wave-uniform but run-time register index (groups are 7 rows, quads 4), which the compiler
+                    // turns into four v_cndmask per row: 1.777 us.
+                    if (R.owner) gstore_sv<uint32_t>(blur0 + (int64_t)(o >> 2) * (4 * A.blur_pitch) + ((o & 3) << 2), out_off, outw);
                 }
                 if (o >= fy0 && o <= fy1) {
                     // compass reject, two pixels per packed-int16 op (see k_fast_blur_band): survive iff one of N, S AND one
@@ -435,19 +482,22 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             int my = incl - cnt;                                       // global number of this lane's next survivor
             for (int r0 = 0; r0 < total; r0 += kQ1) {
                 // append the survivors numbered r0 .. r0 + kQ1 - 1
+                // (this loop runs as many trips as the busiest lane has survivors, with few lanes active: it only records
+                // (lane, bit); the dense side below turns that into pixel and row)
                 while (accw && my < r0 + kQ1) {
                     const int b = 31 - __clz(accw);
                     accw &= ~(1u << b);
-                    const int hi16 = b >> 4, bb = 15 - (b & 15);
-                    const int u = bb >> 1, px = ((bb & 1) << 1) | hi16;
-                    s_q1[my - r0] = (uint32_t)(4 * lane + px) | ((uint32_t)(o_lo + u) << 8);
+                    s_q1[my - r0] = lane_hi | (uint32_t)b;
                     my++;
                 }
                 wave_sync();
                 const int qn = min(kQ1, total - r0);
                 for (int i0 = 0; i0 < qn; i0 += 64) {
                     const int i = i0 + lane;
-                    const uint32_t e = i < qn ? s_q1[i] : 0u;
+                    const uint32_t eq = i < qn ? s_q1[i] : 0u;
+                    // bit b of accw -> step u, pixel px (see accw above)
+                    const int b = (int)(eq & 31u), hi16 = b >> 4, bb = 15 - (b & 15);
+                    const uint32_t e = ((eq >> 6) + (uint32_t)(((bb & 1) << 1) | hi16)) | ((uint32_t)(o_lo + (bb >> 1)) << 8);    // local px | row << 8
                     int sc = 0;
                     if (i < qn) sc = fast_score_ring(s_rawb, (int)(e & 0xFFu), (int)(e >> 8));
                     const bool corner = i < qn && sc >= thr;
@@ -471,7 +521,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             asm volatile("" : "+v"(cur[u]) : : "memory");      // here, not sunk to the loop end behind this group's stores
         }
 #pragma unroll
-        for (int u = 0; u < 7; u++) pre[u] = *reinterpret_cast<const u32_unaligned*>(row_ptr(t0 + 14 + u) + in_off);
+        for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t0 + 14 + u), in_off);
         PHASE(5);
         if (q2n > kQ2) { dense = true; }
         if (dense) q2n = 0;
@@ -581,7 +631,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                         outw = __builtin_amdgcn_perm(v, outw, put[i]);
                         hprev[i] = h1;
                     }
-                    { uint8_t* orow = next0 + (int64_t)dy_next * A.next_pitch; *reinterpret_cast<uint32_t*>(orow + nout_off) = outw; }
+                    gstore_sv<uint32_t>(next0 + (int64_t)dy_next * A.next_pitch, nout_off, outw);
                 }
                 hprev_row = rb;
                 dy_next++;
@@ -706,7 +756,7 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
         // segment re-ingests 7 rows of its neighbours)
         int n_seg = (int)std::min<int64_t>(std::max<int64_t>((6 * 256 * 12 + panels - 1) / panels, 1), std::max(g.h / 64, 1));
         if (seg_force > 0) n_seg = std::min(std::max(g.h / seg_force, 1), 64);
-        const int seg_rows = (g.h + n_seg - 1) / n_seg;
+        const int seg_rows = ((g.h + n_seg - 1) / n_seg + 3) & ~3;      // whole row quads: the lines of a quad of the blurred level are written by one wave
         n_seg = (g.h + seg_rows - 1) / seg_rows;
         const int64_t panels8 = (panels + 7) / 8;
         const int64_t waves = 8 * panels8 * n_seg;

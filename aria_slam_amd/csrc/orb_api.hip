@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "orb_kernels.h"
+#include "orb_device.h"
 
 namespace aria {
 char* last_hip_error_buf() {
@@ -627,6 +628,15 @@ int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* hos
     const LevelGeom& g = h->plan.lv[level];
     const uint8_t* src;
     size_t spitch;
+    if (blurred && h->ctx.last_blur_q4) {
+        // the batch path keeps blurred levels in Q4 order (orb_device.h): fetch the row quads, put the rows back in order
+        const int hq = (g.h + 3) & ~3;
+        std::vector<uint8_t> tmp((size_t)g.pitch * hq);
+        ARIA_HIP(hipMemcpy(tmp.data(), h->D.blur + g.blur_off, tmp.size(), hipMemcpyDeviceToHost));
+        for (int y = 0; y < g.h; y++)
+            for (int x = 0; x < g.w; x++) host_out[(size_t)y * g.w + x] = tmp[(size_t)q4_offset(x, y, g.pitch)];
+        return ARIA_OK;
+    }
     if (blurred) { src = h->D.blur + g.blur_off; spitch = (size_t)g.pitch; }
     else if (level == 0) { src = h->last_src.img; spitch = (size_t)h->last_src.row_stride; }
     else { src = h->D.raw + g.raw_off; spitch = (size_t)g.pitch; }

@@ -111,6 +111,7 @@ struct LaunchCtx {
     // entry point for its last pass only
     hipEvent_t stage_event[4] = {};
     bool stage_events_armed = false;
+    bool last_blur_q4 = false;         // the most recent pass left the blurred levels in Q4 order (orb_device.h): k_fast_blur_stream does
     const char* last_fast_blur = "";   // name of the FAST/blur kernel the most recent pass launched (aria_orb_fast_blur_kernel)
     hipStream_t side[kLevels] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kLevels] = {}, ev_lvl[kLevels] = {};

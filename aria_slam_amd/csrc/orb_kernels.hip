@@ -762,7 +762,12 @@ constexpr int kDescArenaBlocks = 32;
 // (130 VGPRs = three waves per SIMD. Capping at 128 -- amdgpu_waves_per_eu(4), 120 used, no spills -- makes this stage 7 %
 // faster on its own, 0.96 -> 0.89 us/frame, but not the two-stream pipeline: 268.0-269.0k frames/s without the cap,
 // 266.3-269.1k with it, and the FAST/blur kernel beside the matcher then measures 0.160 instead of 0.163. Left uncapped.)
-template <int MODE>
+// Q4: the blurred levels are in Q4 order (orb_device.h; the batch path with k_fast_blur_stream): the window is 10 x 10
+// pieces of 16 bytes (4 rows x 4 px each, 16-byte aligned by construction), 7 loads per lane instead of 10, and lands in a
+// 40 x 40 row-major LDS window. Row-major levels (band kernel: single-frame schedule, tiny images): 37 rows x 64 bytes.
+constexpr int kDescQ = 10;                   // row quads and dword columns of the Q4 window
+constexpr int kDescPitchQ = 4 * kDescQ;      // 40
+template <int MODE, bool Q4>
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S, const uint8_t* __restrict__ raw,
                                                   const uint8_t* __restrict__ blur, const uint4* __restrict__ sel,
                                                   const int* __restrict__ sel_cnt, aria_keypoint* __restrict__ kps,
@@ -775,8 +780,10 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     DSTAMP(0);
     // One LDS window per keypoint, used twice: first the raw 31 x 48 window (IC moments), then -- once the moments are
     // reduced -- the blurred 37 x 64 window, which has been waiting in registers since both were requested together.
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[kDescKp][kDescRows * kDescPitch];
-    uint8_t (*s_raw)[kDescRows * kDescPitch] = s_patch;
+    constexpr int kPatchBytes = Q4 ? kDescPitchQ * kDescPitchQ : kDescRows * kDescPitch;      // >= 31 * kIcPitch either way
+    static_assert(kPatchBytes >= 31 * kIcPitch && kPatchBytes % 16 == 0, "the raw window shares the allocation");
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[kDescKp][kPatchBytes];
+    uint8_t (*s_raw)[kPatchBytes] = s_patch;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
     // regular pass: one call (the grid is the work); arena pass: a small fixed grid strides over the arena's blocks. The body
@@ -866,9 +873,22 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     //      row repeat a (row, piece) that another lane or step also holds. The windows end <= 45 px right of a
     //      keypoint that is >= 31 px inside the level, on rows >= 16 above the last: never past the image. ----
     const uint8_t* bl = blur + (int64_t)frame * P.blur_frame_bytes + g.blur_off;
-    const int xs = (x - kDescR) & ~15;                     // 16-byte aligned first column (pitch and bases are too)
-    DwordQuad pv[10];                                      // blurred window, parked in registers until the moments are done
-    {
+    const int xs = Q4 ? ((x - kDescR) & ~3) : ((x - kDescR) & ~15);     // first window column: dword / 16-byte aligned (pitch and bases are too)
+    const int ys = Q4 ? ((y - kDescR) & ~3) : (y - kDescR);            // first window row
+    constexpr int kPv = Q4 ? 7 : 10;
+    DwordQuad pv[kPv];                                     // blurred window, parked in registers until the moments are done
+    int pq[kPv], pc[kPv];                                  // Q4: (row quad, dword column) of the lane's pieces; 100 pieces, 112 lane slots: the last ones repeat piece 99
+    if constexpr (Q4) {
+        const int64_t qp = (int64_t)g.pitch * 4;
+        const uint8_t* gp = bl + (int64_t)(ys >> 2) * qp + (xs >> 2) * 16;
+#pragma unroll
+        for (int k = 0; k < kPv; k++) {
+            const int p = min(16 * k + l16, kDescQ * kDescQ - 1);
+            pq[k] = (p * 205) >> 11;                        // p / 10 for p < 1024
+            pc[k] = p - kDescQ * pq[k];
+            pv[k] = *reinterpret_cast<const DwordQuad*>(gp + pq[k] * qp + pc[k] * 16);
+        }
+    } else {
         const int r4 = l16 >> 2, c4 = l16 & 3;             // lane -> (row mod 4, piece): four whole rows per instruction
         const int64_t p64 = g.pitch;
         const uint8_t* gp = bl + (int64_t)(y - kDescR) * p64 + xs + 16 * c4;
@@ -877,6 +897,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
             const int row = (4 * k + 4 <= kDescRows) ? 4 * k + r4 : min(4 * k + r4, kDescRows - 1);
             pv[k] = *reinterpret_cast<const DwordQuad*>(gp + row * p64);
         }
+        (void)pq; (void)pc;
     }
     const int rr = l16 / 3, cc = l16 - 3 * rr;             // raw window: lane -> (row mod 5, piece), five rows per instruction
     int pitch;
@@ -954,7 +975,15 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     det_sincos((double)ang, sd, cd);
     const float a = (float)cd, b = (float)sd;
     __builtin_amdgcn_wave_barrier();                       // every lane of the wave is done reading the raw window
-    {
+    constexpr int kPitchL = Q4 ? kDescPitchQ : kDescPitch;
+    if constexpr (Q4) {
+        uint8_t* sp = s_patch[wv * 4 + grp];
+#pragma unroll
+        for (int k = 0; k < kPv; k++) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(sp + (4 * pq[k]) * kPitchL + 4 * pc[k]);    // piece = 4 rows of one dword column
+            d[0] = pv[k].a; d[kPitchL / 4] = pv[k].b; d[2 * kPitchL / 4] = pv[k].c; d[3 * kPitchL / 4] = pv[k].d;
+        }
+    } else {
         const int r4 = l16 >> 2, c4 = l16 & 3;
         uint8_t* sp = s_patch[wv * 4 + grp] + 16 * c4;
 #pragma unroll
@@ -963,7 +992,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
             *reinterpret_cast<uint4*>(sp + row * kDescPitch) = make_uint4(pv[k].a, pv[k].b, pv[k].c, pv[k].d);
         }
     }
-    const uint8_t* bc = s_patch[wv * 4 + grp] + kDescR * kDescPitch + (x - xs);     // window address of the keypoint centre
+    const uint8_t* bc = s_patch[wv * 4 + grp] + (y - ys) * kPitchL + (x - xs);     // window address of the keypoint centre
     __builtin_amdgcn_wave_barrier();
     // Both samples of a test ride in one register pair: (fx0, fx1) = (px0, px1) * a + (py0, py1) * (-b) and
     // (fy0, fy1) = (px0, px1) * b + (py0, py1) * a -- packed multiplies and adds, each rounded once like the
@@ -975,7 +1004,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
     const f2 magic = {12582912.0f, 12582912.0f};
     constexpr uint32_t kMagicBits = 0x4B400000u;          // bits of 1.5 * 2^23
     // mad_u24(by, pitch, bx) = ((by & 0xFFFFFF) * pitch) + bx = (0x400000 + iy) * pitch + kMagicBits + ix
-    const uint8_t* bc0 = bc - (size_t)(0x400000u * (uint32_t)kDescPitch + kMagicBits);
+    const uint8_t* bc0 = bc - (size_t)(0x400000u * (uint32_t)kPitchL + kMagicBits);
     DSTAMP(4);
     uint32_t mine = 0;
 #pragma unroll
@@ -985,8 +1014,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
         const f2 PX = {px0, px1}, PY = {py0, py1};
         const f2 fx = PX * aa + PY * nbb + magic;
         const f2 fy = PX * bb + PY * aa + magic;
-        const uint32_t o0 = __umul24(__float_as_uint(fy.x), kDescPitch) + __float_as_uint(fx.x);
-        const uint32_t o1 = __umul24(__float_as_uint(fy.y), kDescPitch) + __float_as_uint(fx.y);
+        const uint32_t o0 = __umul24(__float_as_uint(fy.x), kPitchL) + __float_as_uint(fx.x);
+        const uint32_t o1 = __umul24(__float_as_uint(fy.y), kPitchL) + __float_as_uint(fx.y);
         const int t0 = bc0[o0];
         const int t1 = bc0[o1];
         const unsigned long long m = __ballot(t0 < t1);
@@ -1157,6 +1186,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     // ARIA_PYRAMID_IMPL) or when the band kernel is not the one in use (tile kernel, per-level side streams).
     const bool latency = latency_schedule(ctx, prof);
     const bool fuse_resize = E.fuse_resize != 0 && !latency;
+    ctx.last_blur_q4 = false;
     if (!latency) {
         hipMemsetAsync(D.ovf, 0, sizeof(int) * (4 + kLevels * (size_t)n_frames), st);    // arena counters + candidate counters (adjacent)
         if (ctx.hdr) hipMemsetAsync(ctx.hdr, 0, 64, st);                                  // single-frame result header
@@ -1178,6 +1208,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
     if (prof) prof->begin(STAGE_FAST_BLUR, st);
     if (E.batch_stream && fuse_resize && stream_eligible(P, S)) {
         ctx.last_fast_blur = "k_fast_blur_stream";
+        ctx.last_blur_q4 = true;
         launch_fast_blur_stream(P, S, D, n_frames, st, prof, ctx);
 #ifdef ARIA_VARIANTS
     } else if (E.fast_blur_impl == 1 && !E.level_streams && P.tie_mode <= 1) {
@@ -1241,15 +1272,22 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
         unsigned long long* stp = (ctx.d_desc_stamps && nwaves <= (1u << 22)) ? ctx.d_desc_stamps : nullptr;
         if (stp) hipMemsetAsync(stp, 0, sizeof(unsigned long long) * 8 * nwaves, st);
         if (latency) {
-            ARIA_LAUNCH(prof, k_describe<2>, dim3((unsigned)(bpf * frames8 + kDescArenaBlocks)), dim3(64 * kDescWaves), 0, st, P, S,
+            ARIA_LAUNCH(prof, (k_describe<2, false>), dim3((unsigned)(bpf * frames8 + kDescArenaBlocks)), dim3(64 * kDescWaves), 0, st, P, S,
                         D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp,
                         (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
-        } else {
-            ARIA_LAUNCH(prof, k_describe<0>, dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
+        } else if (ctx.last_blur_q4) {
+            ARIA_LAUNCH(prof, (k_describe<0, true>), dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
                         D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
                         (const int*)nullptr, 0);
             // arena pass of the tie-storm fallback: every block finds the arena empty on ordinary images
-            ARIA_LAUNCH(prof, k_describe<1>, dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
+            ARIA_LAUNCH(prof, (k_describe<1, true>), dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
+                        D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
+                        (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
+        } else {
+            ARIA_LAUNCH(prof, (k_describe<0, false>), dim3((unsigned)(bpf * frames8)), dim3(64 * kDescWaves), 0, st, P, S, D.raw, D.blur,
+                        D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf, stp, (const uint4*)nullptr,
+                        (const int*)nullptr, 0);
+            ARIA_LAUNCH(prof, (k_describe<1, false>), dim3(256), dim3(64 * kDescWaves), 0, st, P, S,
                         D.raw, D.blur, D.sel, D.sel_cnt, d_kps, d_desc, d_counts, kp_cap, D.err, n_frames, bpf,
                         (unsigned long long*)nullptr, (const uint4*)D.osel, (const int*)D.ovf, D.osel_cap);
         }

@@ -119,7 +119,7 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
         g.raw_off = raw;
         if (l >= 1) raw += (int64_t)g.pitch * g.h;
         g.blur_off = blur;
-        blur += (int64_t)g.pitch * g.h;
+        blur += (int64_t)g.pitch * ((g.h + 3) & ~3);     // whole row quads: the batch path stores the blurred level in Q4 order (orb_device.h)
         pix += (int64_t)g.w * g.h;
         if (l >= 1) {
             const LevelGeom& s = P->lv[l - 1];
