@@ -315,55 +315,80 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     int nms_done = fy0 - 1;      // rows <= this have been through NMS (diagnostic-free: the dense path starts after it)
 
     // ---- candidates leave through an out-list in LDS, 64 at a time, and the global append is split in two: the slice of
-    //      the frame's list is reserved now (one returning atomic per frame in the batch, NOT waited for), the records are
-    //      stored at the NEXT flush, groups later. A wave never sits out an L2 atomic round trip (1-2 us each, once per
-    //      group of rows, was a sixth of this kernel's time). ----
+    //      the frame's list is reserved in the NMS phase (one returning atomic per frame in the batch, NOT waited for), the
+    //      records are stored after the next rows have been taken out of their registers, a phase later. A wave never sits
+    //      out an L2 atomic round trip (1-2 us each, once per group of rows, was a sixth of this kernel's time). ----
     int outn = 0;                        // entries in the out-list (wave-uniform)
     uint32_t p_rec = 0, p_leader = 0, p_rank = 0;   // the batch whose slice has been requested: one entry per lane
     int p_frame = 0, p_base = 0;
     bool p_valid = false;
-    auto complete_pending = [&]() {
-        const int base = __builtin_amdgcn_ds_bpermute((int)(p_leader << 2), p_base);
-        if (p_valid) {
-            const int at = base + (int)p_rank;
-            if (at < A.cand_cap) A.cand[(int64_t)p_frame * A.cand_fstride + at] = p_rec;
+    bool pend_any = false;               // a batch is waiting for its slice (wave-uniform)
+    // the first min(outn, 64) entries of the out-list, one per lane: record, frame, and per frame of the batch the leader
+    // lane, the rank inside the frame's slice and (in the leader) the size of the slice
+    auto take_batch = [&](uint32_t& rec, int& frame, bool& valid, uint32_t& leader, uint32_t& rank, int& my_count) {
+        const int nb = min(outn, 64);
+        valid = lane < nb;
+        rec = valid ? s_out[lane] : 0u;
+        frame = frame0 + (int)(valid ? s_outf[lane] : 0u);
+        unsigned long long pend = __builtin_amdgcn_ballot_w64(valid);
+        my_count = 0; leader = 0; rank = 0;
+        while (pend) {
+            const int ld = __ffsll((long long)pend) - 1;
+            const int f = __builtin_amdgcn_readlane(frame, ld);
+            const bool mine = valid && frame == f;
+            const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
+            if (mine) {
+                leader = (uint32_t)ld;
+                rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            }
+            if (lane == ld) my_count = __popcll(mm);
+            pend &= ~mm;
+        }
+    };
+    auto drop_batch = [&]() {            // entries 64.. move to the front
+        const int nb = min(outn, 64);
+        const uint32_t mr = lane + 64 < outn ? s_out[lane + 64] : 0u, mf = lane + 64 < outn ? s_outf[lane + 64] : 0u;
+        wave_sync();
+        if (lane + 64 < outn) { s_out[lane] = mr; s_outf[lane] = mf; }
+        outn -= nb;
+        wave_sync();
+    };
+    auto store_batch = [&](uint32_t rec, int frame, bool valid, uint32_t leader, uint32_t rank, int base_of_leader) {
+        const int base = __builtin_amdgcn_ds_bpermute((int)(leader << 2), base_of_leader);
+        if (valid) {
+            const int at = base + (int)rank;
+            if (at < A.cand_cap) A.cand[(int64_t)frame * A.cand_fstride + at] = rec;
             else atomicOr(A.err, ERRBIT_CAND_OVERFLOW);
         }
-        p_valid = false;
     };
-    auto flush_out = [&](bool all) {
+    // The ONE place a slice is reserved without waiting (end of the NMS phase) and the ONE place its result is read (after
+    // the next rows have left their registers): inlined more than once, the compiler merges the copies' result registers
+    // with moves, and a move of a pending atomic result is an s_waitcnt vmcnt(0).
+    auto flush_async = [&]() {
+        wave_sync();
+        int my_count;
+        take_batch(p_rec, p_frame, p_valid, p_leader, p_rank, my_count);
+        if (my_count > 0) p_base = atomicAdd(A.cand_cnt + p_frame * kLevels, my_count);
+        pend_any = true;
+        drop_batch();
+    };
+    auto complete_pending = [&]() {
+        store_batch(p_rec, p_frame, p_valid, p_leader, p_rank, p_base);
+        p_valid = false;
+        pend_any = false;
+    };
+    // the out-list is full in the middle of an NMS phase (more than ~64 candidates from one group of rows: corner-dense
+    // images), or the wave is done: reserve, wait, store
+    auto flush_sync = [&](bool all) {
         wave_sync();
         while (outn >= (all ? 1 : 64)) {
-            complete_pending();
-            const int nb = min(outn, 64);
-            p_valid = lane < nb;
-            p_rec = p_valid ? s_out[lane] : 0u;
-            p_frame = frame0 + (int)(p_valid ? s_outf[lane] : 0u);
-            // per frame of the batch: leader lane, rank inside the frame's slice, size of the slice; then ONE atomic
-            // instruction in which every leader reserves its frame's slice -- its result is first read at the next flush
-            unsigned long long pend = __builtin_amdgcn_ballot_w64(p_valid);
-            int my_count = 0;
-            while (pend) {
-                const int ld = __ffsll((long long)pend) - 1;
-                const int f = __builtin_amdgcn_readlane(p_frame, ld);
-                const bool mine = p_valid && p_frame == f;
-                const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
-                if (mine) {
-                    p_leader = (uint32_t)ld;
-                    p_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                }
-                if (lane == ld) my_count = __popcll(mm);
-                pend &= ~mm;
-            }
-            if (my_count > 0) p_base = atomicAdd(A.cand_cnt + p_frame * kLevels, my_count);
-            // entries 64.. move to the front
-            const uint32_t mr = lane + 64 < outn ? s_out[lane + 64] : 0u, mf = lane + 64 < outn ? s_outf[lane + 64] : 0u;
-            wave_sync();
-            if (lane + 64 < outn) { s_out[lane] = mr; s_outf[lane] = mf; }
-            outn -= nb;
-            wave_sync();
+            uint32_t rec, leader, rank; int frame, my_count; bool valid;
+            take_batch(rec, frame, valid, leader, rank, my_count);
+            int base = 0;
+            if (my_count > 0) base = atomicAdd(A.cand_cnt + frame * kLevels, my_count);
+            store_batch(rec, frame, valid, leader, rank, base);
+            drop_batch();
         }
-        if (all) complete_pending();
     };
 
     const int G = (t_last - t_first + 1 + 6) / 7;
@@ -514,15 +539,6 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         }
         wave_sync();
         PHASE(2);
-        // ---- next group's rows out of their registers (mirrored bytes in place), loads of the group after that ----
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
-            asm volatile("" : "+v"(cur[u]) : : "memory");      // here, not sunk to the loop end behind this group's stores
-        }
-#pragma unroll
-        for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t0 + 14 + u), in_off);
-        PHASE(5);
         if (q2n > kQ2) { dense = true; }
         if (dense) q2n = 0;
 
@@ -536,7 +552,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             keep = keep && (li >> 31) && X >= kEdgeThreshold && X < w - kEdgeThreshold && row >= max(kEdgeThreshold, r0) && row < min(h - kEdgeThreshold, r1);
             const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
             if (km) {
-                if (outn > kOut - 64) flush_out(false);
+                if (outn > kOut - 64) flush_sync(false);
                 const int at = outn + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
                 if (keep) {
                     s_out[at] = (uint32_t)X | ((uint32_t)row << 11) | ((uint32_t)sc << 22);
@@ -584,8 +600,24 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             }
         }
         nms_done = max(nms_done, nms_hi);
+        if (outn >= 64) flush_async();        // (the pending batch of the previous group was stored after its rows-in phase)
         wave_sync();
         PHASE(3);
+        // ---- next group's rows out of their registers (mirrored bytes in place), loads of the group after that ----
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
+            asm volatile("" : "+v"(cur[u]) : : "memory");      // here, not sunk to the loop end behind this group's stores
+        }
+#pragma unroll
+        for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t0 + 14 + u), in_off);
+        PHASE(5);
+        // the batch whose slice this group's NMS phase reserved: the waits of the rows above have outlasted its atomic (vmcnt
+        // counts in order), so the result is read here for free. It must not stay in its register across the loop's back
+        // edge: the compiler copies loop-carried values there, and the copy of a pending atomic result is an
+        // s_waitcnt vmcnt(0) in EVERY group -- prefetched rows, pyramid stores, everything (3.2k of a group's 13.9k cycles by
+        // the phase stamps).
+        if (pend_any) { complete_pending(); }
 
         // ---- a6.1 fused: rows of level l+1 whose two source rows are in the ring now. The lane that hosts an output dword
         //      blends its 4 pixels from the ring (v_perm + v_dot2_u32_u16, the integers of k_resize_lds); the horizontal
@@ -639,7 +671,8 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         }
         PHASE(4);
     }
-    flush_out(true);
+    if (pend_any) complete_pending();
+    flush_sync(true);
 #ifdef ARIA_DIAG
     if (stamps && lane == 0) {
 #pragma unroll
