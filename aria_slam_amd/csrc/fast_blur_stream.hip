@@ -445,27 +445,18 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                     // floor(x) = x - fract(x), an integer, which the same conversion leaves alone.
                     constexpr float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
                     uint32_t outw = 0;
-                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    // (Written pixel by pixel on purpose. The same arithmetic on float2 values -- which the compiler turns into
+                    // v_pk_add_f32 with op_sel-swizzled register pairs -- gave a few wrong blurred pixels per ~1000 frames
+                    // whenever the matcher's MFMA waves shared the SIMDs, and never alone: tools/race_probe.py,
+                    // tests/test_gpu_stream.py::test_extraction_beside_the_matcher_equals_extraction_alone.)
 #pragma unroll
-                    for (int p = 0; p < 2; p++) {          // two pixels per v_pk_add_f32
-                        const int j = 2 * p;
-                        const f2 c = {RF[sC][j], RF[sC][j + 1]};
-                        const f2 s1 = f2{RF[sM1][j], RF[sM1][j + 1]} + f2{RF[sP1][j], RF[sP1][j + 1]};
-                        const f2 s2 = f2{RF[sM2][j], RF[sM2][j + 1]} + f2{RF[sP2][j], RF[sP2][j + 1]};
-                        const f2 s3 = f2{RF[sM3][j], RF[sM3][j + 1]} + f2{RF[sP3][j], RF[sP3][j + 1]};
-                        // (v_pk_fma_f32 for these: 8 SGPRs of constants, no faster -- 1.704 against 1.700 us per frame)
-                        f2 acc;
-                        acc.x = TAIL ? __builtin_fmaf(k0, c.x, tb[j]) : k0 * c.x;
-                        acc.y = TAIL ? __builtin_fmaf(k0, c.y, tb[j + 1]) : k0 * c.y;
-                        acc.x = __builtin_fmaf(k1, s1.x, acc.x); acc.y = __builtin_fmaf(k1, s1.y, acc.y);
-                        acc.x = __builtin_fmaf(k2, s2.x, acc.x); acc.y = __builtin_fmaf(k2, s2.y, acc.y);
-                        acc.x = __builtin_fmaf(k3, s3.x, acc.x); acc.y = __builtin_fmaf(k3, s3.y, acc.y);
-                        if (TAIL) {
-                            acc.x = __builtin_fmaf(-__builtin_amdgcn_fractf(acc.x), tm[j], acc.x);
-                            acc.y = __builtin_fmaf(-__builtin_amdgcn_fractf(acc.y), tm[j + 1], acc.y);
-                        }
-                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, j, outw);
-                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, j + 1, outw);
+                    for (int j = 0; j < 4; j++) {
+                        float acc = TAIL ? __builtin_fmaf(k0, RF[sC][j], tb[j]) : k0 * RF[sC][j];
+                        acc = __builtin_fmaf(k1, RF[sM1][j] + RF[sP1][j], acc);
+                        acc = __builtin_fmaf(k2, RF[sM2][j] + RF[sP2][j], acc);
+                        acc = __builtin_fmaf(k3, RF[sM3][j] + RF[sP3][j], acc);
+                        if (TAIL) acc = __builtin_fmaf(-__builtin_amdgcn_fractf(acc), tm[j], acc);
+                        outw = __builtin_amdgcn_cvt_pk_u8_f32(acc, j, outw);
                     }
                     // Q4 order (orb_device.h): dword column gdw of row o at (o >> 2) * 4 * pitch + 16 gdw + 4 (o & 3). What the
                     // layout costs HERE (640x480, 8192 frames, rocprofv3, one box): row-major 1.626 us per frame, Q4 1.703

@@ -190,10 +190,12 @@ def verify_last_step(A, torch, dev, images, last, halo_img, B, W, H, NF, cap, ra
         if key in g and abs(g[key]["ratio"] - ratio) < 1e-9:
             n = min(B, g[key]["frames"])
             bad = [f for f in range(n) if fd[f][:len(g[key]["frame"][f])] != g[key]["frame"][f]]
-            bad += [f for f in range(1, n) if md[f][:len(g[key]["match"][f])] != g[key]["match"][f]]
+            badm = [f for f in range(1, n) if md[f][:len(g[key]["match"][f])] != g[key]["match"][f]]
             res["oracle_prefix_frames"] = n
             if bad:
                 res["problems"].append("frames %s differ from the oracle digests" % sorted(set(bad))[:8])
+            if badm:
+                res["problems"].append("matches of pairs (f, f-1), f in %s differ from the oracle digests" % sorted(set(badm))[:8])
             full = g[key].get("full", {}).get(str(B))
             if full is not None:
                 res["full_checksum_matches_committed"] = (full == res["checksum_of_checksums"])

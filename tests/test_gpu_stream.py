@@ -178,3 +178,49 @@ def test_level_size_mode_follows_the_parameter(aria, oracle, torch_cuda, w, h):
         assert ok0.tobytes() != ok.tobytes()                      # the switch matters at this size
     finally:
         e.close()
+
+
+def test_extraction_beside_the_matcher_equals_extraction_alone(aria, torch_cuda):
+    """bench.py's two-stream schedule: the FAST/blur launches of one step run while the matcher's MFMA waves of the previous
+    step share the SIMDs. A batch extracted that way must equal the same batch extracted alone, byte for byte (round 3: a
+    float2 formulation of the blur's column pass -- v_pk_add_f32 with op_sel-swizzled register pairs -- produced a few
+    wrong blurred pixels per ~1000 frames ONLY in this situation; tools/race_probe.py prints what differs)."""
+    torch = torch_cuda
+    W, H, NF, B = 640, 480, 2000, 2048
+    dev = torch.device("cuda", 0)
+    host = torch.empty((B, H, W), dtype=torch.uint8)
+    aria.synth_sequence(1, B // 2, W, H, out=host.numpy())
+    img = host.to(dev)
+    se, sm = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    e = aria.OrbHipExtractor(max_features=NF, max_width=W, max_height=H, max_batch=B, stream=se.cuda_stream)
+    m = aria.HipMatcher(stream=sm.cuda_stream, max_query=4096, max_train=4096)
+    try:
+        cap = e.kp_capacity()
+
+        def bufs():
+            return (torch.zeros((B, cap, 24), dtype=torch.uint8, device=dev),
+                    torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
+        k0, d0, c0 = bufs()
+        with torch.cuda.stream(se):
+            e.extract_batch_device(img, B, W, H, k0, d0, c0, cap)
+        torch.cuda.synchronize()
+        assert e.fast_blur_kernel() == "k_fast_blur_stream"
+        mt = torch.empty((B, cap, 12), dtype=torch.uint8, device=dev)
+        nm = torch.zeros(B, dtype=torch.int32, device=dev)
+        k1, d1, c1 = bufs()
+        for rep in range(3):
+            with torch.cuda.stream(sm):
+                for _ in range(2):
+                    m.match_batch_device(d0.data_ptr() + cap * 32, c0.data_ptr() + 4, d0, c0, B - 1, cap * 32, 0.75,
+                                         mt.data_ptr() + cap * 12, nm.data_ptr() + 4, cap)
+            with torch.cuda.stream(se):
+                e.extract_batch_device(img, B, W, H, k1, d1, c1, cap)
+            torch.cuda.synchronize()
+            e.check()
+            assert torch.equal(c0, c1), rep
+            assert torch.equal(k0, k1), rep
+            bad = (d0 != d1).flatten(1).any(dim=1).nonzero().flatten().tolist()
+            assert not bad, (rep, bad[:8])
+    finally:
+        e.close()
+        m.close()
