@@ -463,7 +463,8 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                     // (levels 0-2 +9 / +6 / +6 %, levels 5-7 < 2 %; HBM bytes written +4.7 %, fetched the same) -- against
                     // 0.127 us less in k_describe. Collecting the four rows of a quad in registers for one 16-byte store
                     // needs a wave-uniform but run-time register index (groups are 7 rows, quads 4), which the compiler
-                    // turns into four v_cndmask per row: 1.777 us.
+                    // turns into four v_cndmask per row: 1.777 us; parking them in LDS under that index and storing 16 bytes
+                    // per quad: +8 %; non-temporal stores: +35 % (the L2 no longer merges the rows of a line).
                     if (R.owner) gstore_sv<uint32_t>(blur0 + (int64_t)(o >> 2) * (4 * A.blur_pitch) + ((o & 3) << 2), out_off, outw);
                 }
                 if (o >= fy0 && o <= fy1) {
