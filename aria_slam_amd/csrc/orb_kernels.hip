@@ -1297,7 +1297,7 @@ void launch_extract_chunk(const Plan& P, const FrameSrc& S, const DeviceScratch&
             hipMemcpy(hs.data(), stp, hs.size() * 8, hipMemcpyDeviceToHost);
             double ph[6] = {0}; size_t n = 0;
             for (size_t w = 0; w < nwaves; w++) {
-                if (!hs[w * 8 + 6]) continue;      // wave left early (empty slots)
+                if (!hs[w * 8 + 6] || !hs[w * 8 + 5] || !hs[w * 8 + 1]) continue;      // wave left early (empty slots: only stamps 0 and 6)
                 for (int k = 0; k < 6; k++) ph[k] += (double)(hs[w * 8 + k + 1] - hs[w * 8 + k]);
                 n++;
             }
