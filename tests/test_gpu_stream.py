@@ -210,7 +210,7 @@ def test_extraction_beside_the_matcher_equals_extraction_alone(aria, torch_cuda)
         k1, d1, c1 = bufs()
         for rep in range(3):
             with torch.cuda.stream(sm):
-                for _ in range(2):
+                for _ in range(4):          # long enough to run beside select and describe too
                     m.match_batch_device(d0.data_ptr() + cap * 32, c0.data_ptr() + 4, d0, c0, B - 1, cap * 32, 0.75,
                                          mt.data_ptr() + cap * 12, nm.data_ptr() + 4, cap)
             with torch.cuda.stream(se):
