@@ -703,10 +703,15 @@ def main():
             knn_ms, knn_steps, knn_src = stage_ms["knn2"], args.steps, "timed region"
         else:
             knn_ms, knn_steps, knn_src = all_ms["knn2"], 1, "extra untimed step (the timed region does not bracket the matcher's stream)"
-        matcher_roofline = {"kernel": "k_knn2_mfma (v_mfma_i32_32x32x32_i8 + per-lane top-2)", "bound": "mfma",
+        # train sets up to 4096 rows (every SLAM frame) run on the FP4 matrix path: one E2M1 value per descriptor bit,
+        # v_mfma_f32_32x32x64_f8f6f4; peak = the dense FP4 figure of MI355X_MICROARCH.md (10 PFLOP/s, 2 x the int8 / fp8 one)
+        fp4 = int(cnt_host.max()) <= 4096
+        mpeak = 10000.0 if fp4 else 5000.0
+        matcher_roofline = {"kernel": ("k_knn2_fp4 (v_mfma_f32_32x32x64_f8f6f4 on E2M1 bit operands + per-lane top-2)" if fp4 else
+                                       "k_knn2_mfma (v_mfma_i32_32x32x32_i8 + per-lane top-2)"), "bound": "mfma",
                             "achieved": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12, 1) if knn_ms else None,
-                            "peak": 5000.0, "unit": "TOP/s",
-                            "frac": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12 / 5000.0, 4) if knn_ms else None,
+                            "peak": mpeak, "unit": "TOP/s",
+                            "frac": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12 / mpeak, 4) if knn_ms else None,
                             "measured_in": knn_src,
                             # the matcher's HBM share is tiny (B_match = 32 (Nq + Nt) + 16 Nq per pair) and its
                             # work in the units of the popcount formulation is 8 dword xor+popcounts per descriptor pair
@@ -739,8 +744,8 @@ def main():
             "stage_us_per_frame": {k: round(1e3 * all_ms[k] / max(frames_all, 1), 3) for k in all_ms},
             "stage_us_per_frame_note": "every stage bracketed, one extra untimed step after the timed region; the timed "
                                        "region brackets only fast_blur (achieved / avg_launch_ms), plus knn2 with --no-pipeline",
-            # kNN-2 runs on the matrix cores (knn2_mfma.hip): exact int8 inner products of bit-widened descriptors.
-            # ops = 2 * 256 * sum(nq * nt) per launch; peak = 2 x the dense bf16 MFMA peak (MI355X_MICROARCH.md, I8 row)
+            # kNN-2 runs on the matrix cores (knn2_mfma.hip): exact inner products of bit-widened descriptors (FP4 operands up
+            # to 4096 train rows, int8 beyond). ops = 2 * 256 * sum(nq * nt) per launch
             "matcher": matcher_roofline,
         }
         default_cfg = (W, H, NF, args.pairs) == (640, 480, 2000, 4096)
