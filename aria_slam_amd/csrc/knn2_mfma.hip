@@ -286,6 +286,9 @@ __device__ __forceinline__ void knn2_body_fp4(
     double ratio, int* __restrict__ good, int tsplit) {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][TT * kRowF];
     __shared__ __attribute__((aligned(16))) float s_base[2][TT];
+    __shared__ uint32_t s_lut[256];          // byte -> eight E2M1 nibbles of -2.0 (the train side): widening a staged dword is
+                                             // four LDS reads instead of 32 vector-ALU instructions, which the top-2 updates
+                                             // leave no room for in the MFMAs' shadow (0.510 -> 0.500 us per pair)
     __shared__ int s_cnt;
     constexpr int QB = 128 * NC;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -294,6 +297,8 @@ __device__ __forceinline__ void knn2_body_fp4(
     const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
     const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
     if ((int)blockIdx.x * QB >= nq) return;
+    s_lut[tid] = (uint32_t)spread8((uint32_t)tid, 0xCu);
+    __syncthreads();
     const uint4* qp = reinterpret_cast<const uint4*>(q + (int64_t)pair * q_stride);
     const uint32_t* tw = reinterpret_cast<const uint32_t*>(t + (int64_t)pair * t_stride);
 
@@ -325,7 +330,10 @@ __device__ __forceinline__ void knn2_body_fp4(
     auto store_tile = [&](int it, int buf) {
 #pragma unroll
         for (int k = 0; k < NR; k++) {
-            *reinterpret_cast<v4i*>(&s_a[buf][(sr + 32 * k) * kRowF + ss * 16]) = widen32_fp4(dreg[k], 0xCu);
+            const uint32_t w = dreg[k];
+            v4i wv4;
+            wv4.x = (int)s_lut[w & 0xFFu]; wv4.y = (int)s_lut[(w >> 8) & 0xFFu]; wv4.z = (int)s_lut[(w >> 16) & 0xFFu]; wv4.w = (int)s_lut[w >> 24];
+            *reinterpret_cast<v4i*>(&s_a[buf][(sr + 32 * k) * kRowF + ss * 16]) = wv4;
             const int pt = sum8(__popc(dreg[k])), tt = it * TT + sr + 32 * k;
             s_base[buf][sr + 32 * k] = tt < nt ? (float)(pt + 257) + (float)tt * (1.0f / 4096.0f) : kNoneF;
         }
@@ -430,7 +438,9 @@ __device__ __forceinline__ void knn2_body_fp4(
 // Shapes measured in bench.py's two-stream schedule (frames/s; kNN-2 us per pair): 512 queries per workgroup at 2 waves per
 // SIMD 318.3 k / 0.550, at 3 waves per SIMD (<= 168 VGPRs; the spills are outside the loop) 326.7 k / 0.508, 1024 queries at 2
 // waves 323.3 k / 0.513, 256 queries at 4 waves 307.9 k / 0.567 (and the FAST/blur kernel beside it at 0.16 instead of 0.19);
-// 128-train tiles instead of 64: +0.4 %. The int8 kernel above: 297.3 k / 0.778.
+// 128-train tiles instead of 64: +0.4 %. The int8 kernel above: 297.3 k / 0.778. A software-pipelined inner loop (the MFMAs of
+// column tile c between the top-2 updates of tile c - 1) needs 220 VGPRs = 2 waves per SIMD and measures 0.50 us like this form
+// at 3: the two pipes overlap across waves, not inside one.
 constexpr int kFp4Nc = 4, kFp4Tt = 64;
 template <int MODE, int NC, int TT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == kFp4Nc ? 3 : 2))) void k_knn2_fp4(
