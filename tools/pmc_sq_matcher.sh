@@ -14,7 +14,7 @@ import pandas as pd
 f = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1]
 df = pd.read_csv(f)
 df["k"] = df["Kernel_Name"].str.extract(r"(k_\w+)")[0]
-df = df[df.k.isin(["k_knn2_mfma", "k_ratio_compact"])]
+df = df[df.k.isin(["k_knn2_mfma", "k_knn2_fp4", "k_ratio_compact"])]
 t = df.groupby(["k", "Counter_Name"]).agg(sum=("Counter_Value", "sum"), dispatches=("Counter_Value", "count"))
 print(t.to_string())
 PY
