@@ -498,6 +498,8 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
                       uint2* keys, int maxq, double ratio, int* good, int max_train, int* gate) {
     if (nq_max <= 0 || n_pairs <= 0) return;
     static const int force_nc = [] { const char* e = aria_getenv("ARIA_KNN_NC"); return e ? atoi(e) : 0; }();
+    // variants build: ARIA_KNN_IMPL=int8 keeps the int8 kernel for every train-set size (the product takes the FP4 path up to 4096)
+    static const bool force_i8 = [] { const char* e = aria_getenv("ARIA_KNN_IMPL"); return e && e[0] == 'i'; }();
     const bool wide = max_train > kNarrowMax;      // only built in the 256-query form
     // 512-query workgroups amortise the train staging and the A-fragment reads over twice the MFMAs, but need enough
     // workgroups to fill 256 CUs x 2; small jobs (a single frame pair) take the 256-query form
@@ -520,10 +522,12 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
     }
     if (mode == 0) {
         if (wide) launch_one<0, true, 2, 64>(ARIA_KNN_ARGS);
+        else if (force_i8) { if (nc4) launch_one<0, false, 4, 64>(ARIA_KNN_ARGS); else launch_one<0, false, 2, 64>(ARIA_KNN_ARGS); }
         else if (nc4) launch_one_fp4<0, kFp4Nc, kFp4Tt>(ARIA_KNN_ARGS);
         else launch_one_fp4<0, 2, 64>(ARIA_KNN_ARGS);
     } else {
         if (wide) launch_one<1, true, 2, 64>(ARIA_KNN_ARGS);
+        else if (force_i8) { if (nc4) launch_one<1, false, 4, 64>(ARIA_KNN_ARGS); else launch_one<1, false, 2, 64>(ARIA_KNN_ARGS); }
         else if (nc4) launch_one_fp4<1, kFp4Nc, kFp4Tt>(ARIA_KNN_ARGS);
         else launch_one_fp4<1, 2, 64>(ARIA_KNN_ARGS);
     }
@@ -543,6 +547,8 @@ void launch_knn2_mfma_split(hipStream_t st, const uint8_t* q, int nq, const uint
     const int ntiles = (nt + 63) / 64, per = std::max(1, (ntiles + nsplit - 1) / nsplit);
     if (nt > kNarrowMax)
         launch_one<0, true, 2, 64>(nq, 1, st, q, nq_arr, nq, t, nt_arr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
+    else if (aria_getenv("ARIA_KNN_IMPL") && aria_getenv("ARIA_KNN_IMPL")[0] == 'i')      // variants build only
+        launch_one<0, false, 2, 64>(nq, 1, st, q, nq_arr, nq, t, nt_arr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
     else
         launch_one_fp4<0, 2, 64>(nq, 1, st, q, nq_arr, nq, t, nt_arr, nt, 0, 0, keys, maxq, 0.0, nullptr, per, nsplit);
 }

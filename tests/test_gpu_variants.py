@@ -35,6 +35,7 @@ VARIANTS = [
     {"ARIA_BAND_QPCT0": "1", "ARIA_BAND_QPCT_STEP": "0"},          # survivor queue overflows -> slow path
     {"ARIA_BAND_BUDGET_KB": "160"},                                # several strips per workgroup
     {"ARIA_KNN_IMPL": "valu"},                                     # vector-ALU kNN-2 instead of the matrix-core one
+    {"ARIA_KNN_IMPL": "int8"},                                     # int8 matrix-core kNN-2 instead of the FP4 one
     {"ARIA_SELECT_SORT": "bitonic"},
     {"ARIA_ZERO_COPY": "1"},                                       # single-frame: pyramid kernel reads the pinned host frame itself
     {"ARIA_BAND_XCD_MAP": "0"},                                    # plain (strip, frame) order of the batch FAST/blur workgroups                               # k_select's LDS bitonic sort (fallback of the bin sort)
@@ -52,7 +53,7 @@ def test_variant_matches_golden(env, variants_lib):
     assert out.stdout.count("OK") == 6
 
 
-@pytest.mark.parametrize("env", [{}, {"ARIA_KNN_NC": "2"}, {"ARIA_KNN_NC": "4"}, {"ARIA_KNN_IMPL": "valu"}],
+@pytest.mark.parametrize("env", [{}, {"ARIA_KNN_NC": "2"}, {"ARIA_KNN_NC": "4"}, {"ARIA_KNN_IMPL": "valu"}, {"ARIA_KNN_IMPL": "int8"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_knn2_kernels_against_brute_force(env, variants_lib):
     """Matrix-core kNN-2 in both workgroup shapes (256 / 512 queries), both key layouts (train sets above 4096
