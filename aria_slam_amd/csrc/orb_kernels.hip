@@ -1019,7 +1019,9 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(Plan P, FrameSrc S
         const int t0 = bc0[o0];
         const int t1 = bc0[o1];
         const unsigned long long m = __ballot(t0 < t1);
-        if (l16 == it) mine = (uint32_t)(m >> (16 * grp)) & 0xFFFFu;
+        // lane l16 == it of every group keeps its group's 16 bits; the lane mask is a compile-time constant handed to
+        // v_cndmask as it is (no per-iteration v_cmp)
+        if (__builtin_amdgcn_inverse_ballot_w64(0x0001000100010001ull << it)) mine = (uint32_t)(m >> (16 * grp)) & 0xFFFFu;
     }
     DSTAMP(5);
     if (valid && fits) {
