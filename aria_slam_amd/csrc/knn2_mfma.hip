@@ -299,6 +299,13 @@ __device__ __forceinline__ void knn2_body_fp4(
     if ((int)blockIdx.x * QB >= nq) return;
     s_lut[tid] = (uint32_t)spread8((uint32_t)tid, 0xCu);
     __syncthreads();
+    // (the query side reads the same table: +1.0 = 0010b is -2.0 = 1100b shifted right by two and masked; 0.4985 -> 0.494 us)
+    auto widen_q = [&](uint32_t w) -> v4i {
+        v4i r;
+        r.x = (int)((s_lut[w & 0xFFu] >> 2) & 0x22222222u); r.y = (int)((s_lut[(w >> 8) & 0xFFu] >> 2) & 0x22222222u);
+        r.z = (int)((s_lut[(w >> 16) & 0xFFu] >> 2) & 0x22222222u); r.w = (int)((s_lut[w >> 24] >> 2) & 0x22222222u);
+        return r;
+    };
     const uint4* qp = reinterpret_cast<const uint4*>(q + (int64_t)pair * q_stride);
     const uint32_t* tw = reinterpret_cast<const uint32_t*>(t + (int64_t)pair * t_stride);
 
@@ -315,7 +322,7 @@ __device__ __forceinline__ void knn2_body_fp4(
 #pragma unroll
         for (int s = 0; s < 8; s++) pc += __popc(dw[s]);
 #pragma unroll
-        for (int s = 0; s < 4; s++) B[c][s] = widen32_fp4(hh ? dw[2 * s + 1] : dw[2 * s], 0x2u);
+        for (int s = 0; s < 4; s++) B[c][s] = widen_q(hh ? dw[2 * s + 1] : dw[2 * s]);
         pq[c] = pc;
     }
 
