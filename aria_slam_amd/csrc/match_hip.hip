@@ -24,12 +24,6 @@ using namespace aria;
 
 namespace {
 
-constexpr int kMatchTile = 256;
-#ifndef ARIA_KNN_SCALAR
-#define ARIA_KNN_SCALAR 0   // measured (tools/microbench/valu_rates.hip): v_xor with an SGPR source costs 4.35 cycles per wave-instruction,
-                            // VGPR-VGPR 2.55 -> the LDS-broadcast form is the faster of the two
-#endif
-constexpr bool kUseScalarTrain = ARIA_KNN_SCALAR != 0;
 
 // v_bcnt_u32_b32 dst, src, acc: popcount(src) + acc in one VALU instruction
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
@@ -39,6 +33,12 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
 }
 
 #ifdef ARIA_VARIANTS      // the vector-ALU kNN-2 (round 1's kernel): variants build only, ARIA_KNN_IMPL=valu
+constexpr int kMatchTile = 256;
+#ifndef ARIA_KNN_SCALAR
+#define ARIA_KNN_SCALAR 0   // measured (tools/microbench/valu_rates.hip): v_xor with an SGPR source costs 4.35 cycles per wave-instruction,
+                            // VGPR-VGPR 2.55 -> the LDS-broadcast form is the faster of the two
+#endif
+constexpr bool kUseScalarTrain = ARIA_KNN_SCALAR != 0;
 template <int MODE>   // 0: store the two keys per query; 1: count queries passing the double-precision ratio test
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr, int nq_fixed,
                                               const uint8_t* __restrict__ t, const int* __restrict__ nt_arr, int nt_fixed,
