@@ -59,7 +59,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Left alone the compiler folds the lane's constant offset into a 64-bit VGPR base and pays a v_mad_i64_i32 (and a VGPR
 // pair) per row load and store; the empty asm pins the row base to the scalar unit (243 -> 69 of them in the object; the
 // Q4 build 1.739 -> 1.703 us per frame), the address space keeps the access global (an integer turned pointer would be a
-// FLAT access, which also counts on lgkmcnt).
+// FLAT access, which also counts on lgkmcnt). (Round 4: also pinning the lane offset with an empty "+v" asm keeps its
+// zero-extension in the block, and every row load / store then takes the saddr form -- global_store_dword v_off, v, s[b:b+1]
+// -- instead of a v_lshl_add_u64 per access: 147 VGPRs, no faster: 0.2015 / 0.1992 against 0.2025 / 0.2009 A B A B.)
 template <typename T>
 __device__ __forceinline__ T gload_sv(const uint8_t* base, uint32_t off) {
     uint64_t b = reinterpret_cast<uint64_t>(base);
@@ -109,9 +111,26 @@ __device__ __forceinline__ void wave_sync() {
 // byte offset of level row y inside a ring of kRing rows of 256 bytes (row -3 is slot 0)
 __device__ __forceinline__ int ring_off(int y) { return ((y + 3) & (kRing - 1)) << 8; }
 
+// Tuning switches of this file (A/B builds only; the defaults are the product): see DESIGN.md section 4, round 4.
+#ifndef ARIA_SCORE_F16
+#define ARIA_SCORE_F16 1
+#endif
+#ifndef ARIA_COMPASS2
+#define ARIA_COMPASS2 1
+#endif
+
 // fast_score.cpp cornerScore<16> for local pixel px of row `row` of the wave's raw ring: max over the 16 nine-arcs of
-// min(v - ring) and of min(ring - v), minus 1; both polarities ride in one register as packed int16. The pixel is a
+// min(v - ring) and of min(ring - v), minus 1; both polarities ride in one register as a packed pair. The pixel is a
 // FAST-9 corner for threshold t iff the result is >= t. (k_fast_blur_band's fast_score_pk on ring addresses.)
+//
+// Round 4: the pair is packed HALF FLOATS, not int16. A byte b in the low bits of a half (0x00bb) is the subnormal
+// b * 2^-24 -- the subnormals and the first normal binade of binary16 are one linear ramp up to 0x07ff -- so v_pk_add_f16
+// of (v | ring << 16) and its half-swapped, negated self is exactly (v - ring, ring - v) * 2^-24 (|d| <= 255: exact, the
+// kernel runs with half denormals enabled like every HIP kernel), and gfx950 has THREE-input packed minimum / maximum for
+// halves (v_pk_minimum3_f16 / v_pk_maximum3_f16, same issue class as v_pk_min_i16: profiles/r2_valu_issue_rates.txt):
+// the nine-arc minima are min3 of min3 (32 instructions instead of 64 two-input ones) and the maximum over the 16 arcs is
+// 8 instead of 16. A non-negative result's bit pattern IS the integer; negative ones (sign-magnitude) read as negative
+// int16, and a negative score is never a corner.
 __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int row) {
     const uint8_t* rm3 = ring + ring_off(row - 3) + px; const uint8_t* rm2 = ring + ring_off(row - 2) + px;
     const uint8_t* rm1 = ring + ring_off(row - 1) + px; const uint8_t* c = ring + ring_off(row) + px;
@@ -121,6 +140,29 @@ __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int 
     uint32_t rg[16] = {rp3[0], rp3[1], rp2[2], rp1[3], c[3], rm1[3], rm2[2], rm3[1],
                        rm3[0], rm3[-1], rm2[-2], rm1[-3], c[-3], rp1[-3], rp2[-2], rp3[-1]};
     uint32_t Pk[16];
+#if ARIA_SCORE_F16
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = v | (rg[k] << 16);
+        asm("v_pk_add_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Pk[k]) : "v"(x));
+    }
+    uint32_t M3[16], M9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(M3[k]) : "v"(Pk[k]), "v"(Pk[(k + 1) & 15]), "v"(Pk[(k + 2) & 15]));
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(M9[k]) : "v"(M3[k]), "v"(M3[(k + 3) & 15]), "v"(M3[(k + 6) & 15]));
+    uint32_t A5[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(A5[k]) : "v"(M9[3 * k]), "v"(M9[3 * k + 1]), "v"(M9[3 * k + 2]));
+    A5[5] = M9[15];
+    uint32_t B0, B1, Q;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(B0) : "v"(A5[0]), "v"(A5[1]), "v"(A5[2]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(B1) : "v"(A5[3]), "v"(A5[4]), "v"(A5[5]));
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(Q) : "v"(B0), "v"(B1));
+#else
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         // (v - ring, ring - v) from ONE packed register (v | ring << 16) and itself with the halves swapped (op_sel of the
@@ -140,6 +182,7 @@ __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int 
         const uint32_t m9 = pk_min_i16(pk_min_i16(M4[k], M4[(k + 4) & 15]), Pk[(k + 8) & 15]);
         Q = pk_max_i16(Q, m9);
     }
+#endif
     const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
     return max(q0, q1) - 1;
 }
@@ -477,10 +520,19 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                         const uint32_t c2 = RC2[sC][pr], n2 = RC2[sM3][pr], s2 = RC2[sP3][pr];
                         const uint32_t e2 = __builtin_amdgcn_perm(0u, RE[sC], sl);
                         const uint32_t w2p = __builtin_amdgcn_perm(0u, RW[sC], sl);
+#if ARIA_COMPASS2
+                        // darker: X = max(min(n,s), min(e,w)) < c - t; brighter: Y = min(max(n,s), max(e,w)) > c + t; both in
+                        // one comparison: t - max(c - X, Y - c) < 0 (sign bits 15 / 31)
+                        const uint32_t X = pk_max_i16(pk_min_i16(n2, s2), pk_min_i16(e2, w2p));
+                        const uint32_t Y = pk_min_i16(pk_max_i16(n2, s2), pk_max_i16(e2, w2p));
+                        const uint32_t m = pk_max_i16(pk_sub_i16(c2, X), pk_sub_i16(Y, c2));
+                        pass[pr] = pk_sub_i16(T2, m) & (pr ? R.xm1 : R.xm0);
+#else
                         const uint32_t lo = pk_sub_i16(c2, T2), hi = pk_add_i16(c2, T2);
                         const uint32_t dk = pk_sub_i16(pk_max_i16(pk_min_i16(n2, s2), pk_min_i16(e2, w2p)), lo);
                         const uint32_t br = pk_sub_i16(hi, pk_min_i16(pk_max_i16(n2, s2), pk_max_i16(e2, w2p)));
                         pass[pr] = (dk | br) & (pr ? R.xm1 : R.xm0);
+#endif
                     }
                     accw |= (pass[0] | (pass[1] >> 1)) >> (2 * u);
                 }
