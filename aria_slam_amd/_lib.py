@@ -37,6 +37,11 @@ EXPORTS = [
     "aria_orb_last_device", "aria_matcher_match_device", "aria_matcher_retain_device", "aria_matcher_resident_rows",
     "aria_matcher_match_device_async", "aria_matcher_finish", "aria_kfdb_match", "aria_stream_create", "aria_stream_destroy",
     "aria_orb_fast_blur_kernel", "aria_flag_keypoints_shifted_device",
+    # ABI 4: device memory, staging copies and events for hosts that do not link the HIP runtime (host/ BatchFrontEnd)
+    "aria_device_count", "aria_device_alloc", "aria_device_free", "aria_host_alloc_pinned", "aria_host_free_pinned",
+    "aria_copy_h2d_async", "aria_copy_d2h_async", "aria_copy_d2d_async", "aria_fill_async", "aria_stream_synchronize",
+    "aria_event_create", "aria_event_destroy", "aria_event_record", "aria_stream_wait_event", "aria_event_synchronize",
+    "aria_event_elapsed_ms",
 ]
 
 

@@ -41,6 +41,22 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line) 
         if (e__ != hipSuccess) return aria::hip_fail(e__, #call, __FILE__, __LINE__); \
     } while (0)
 
+// Host-blocking fill / copy ORDERED ON A HANDLE'S STREAM instead of the legacy default stream (plain hipMemset / hipMemcpy).
+// A legacy-stream operation implicitly depends on every blocking stream of the device and fails with "operation would make
+// the legacy stream depend on a capturing blocking stream" while ANOTHER host thread is capturing a hipGraph on one -- the
+// single-frame entry points capture their schedule, and euroc_frontend --shards runs several handles from several threads
+// (seen once in round 4: a matcher being created while a neighbour shard captured). The handles' own streams are also
+// created non-blocking (aria::create_stream) so that nobody else's legacy-stream call can depend on them.
+inline hipError_t memset_on(hipStream_t st, void* p, int v, size_t n) {
+    const hipError_t e = hipMemsetAsync(p, v, n, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+inline hipError_t memcpy_on(hipStream_t st, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+inline hipError_t create_stream(hipStream_t* st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
+
 // deferred error bits written by kernels
 enum : int {
     ERRBIT_CAND_OVERFLOW = 1,   // FAST candidate list of some (frame, level) exceeded cand_cap

@@ -421,7 +421,7 @@ void matcher_free(aria_matcher_s* m) {
 int matcher_alloc(aria_matcher_s* m) {
     const size_t nq = (size_t)std::max(m->max_query, 1), nt = (size_t)std::max(m->max_train, 1);
     ARIA_HIP(hipMalloc(&m->d_err, 2 * sizeof(int)));      // [0] deferred error bits, [1] narrow/wide gate of the batch kNN-2
-    ARIA_HIP(hipMemset(m->d_err, 0, 2 * sizeof(int)));
+    ARIA_HIP(memset_on(m->stream, m->d_err, 0, 2 * sizeof(int)));
     ARIA_HIP(hipMalloc(&m->d_q, nq * 32));
     ARIA_HIP(hipMalloc(&m->d_t, nt * 32));
     ARIA_HIP(hipMalloc(&m->d_m, nq * sizeof(aria_match)));
@@ -480,7 +480,7 @@ int aria_matcher_create(const aria_matcher_config* c, aria_matcher_t* out) {
     if (c->stream) {
         m->stream = (hipStream_t)c->stream;
     } else {
-        hipError_t e = hipStreamCreate(&m->stream);
+        hipError_t e = create_stream(&m->stream);
         if (e != hipSuccess) { delete m; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
         m->owns_stream = true;
     }
@@ -515,7 +515,7 @@ int aria_stream_create(int device, void** stream) {
     if (device < 0 || device >= ndev) return ARIA_E_NO_DEVICE;
     ARIA_HIP(hipSetDevice(device));
     hipStream_t s = nullptr;
-    ARIA_HIP(hipStreamCreate(&s));
+    ARIA_HIP(create_stream(&s));
     *stream = (void*)s;
     return ARIA_OK;
 }
@@ -553,8 +553,8 @@ int aria_matcher_sync(aria_matcher_t m) {
     ARIA_HIP(hipSetDevice(m->device));
     ARIA_HIP(hipStreamSynchronize(m->stream));
     int bits = 0;
-    ARIA_HIP(hipMemcpy(&bits, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (bits) ARIA_HIP(hipMemset(m->d_err, 0, sizeof(int)));
+    ARIA_HIP(memcpy_on(m->stream, &bits, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (bits) ARIA_HIP(memset_on(m->stream, m->d_err, 0, sizeof(int)));
     return errbits_to_status(bits);
 }
 
@@ -961,7 +961,7 @@ int aria_matcher_match_multi(aria_matcher_t m, const uint8_t* q, int nq, const u
         if (cnt[(size_t)c] > cap_per_cand) { status = ARIA_E_OUTPUT_TOO_SMALL; continue; }
         if (cnt[(size_t)c] > 0) {
             if (!matches) return ARIA_E_INVALID;
-            ARIA_HIP(hipMemcpy(matches + (size_t)c * cap_per_cand, m->d_mm + (size_t)c * m->max_query,
+            ARIA_HIP(memcpy_on(m->stream, matches + (size_t)c * cap_per_cand, m->d_mm + (size_t)c * m->max_query,
                                sizeof(aria_match) * (size_t)cnt[(size_t)c], hipMemcpyDeviceToHost));
         }
     }
@@ -1012,14 +1012,14 @@ int aria_kfdb_create(int device, void* stream, int capacity, int rows, aria_kfdb
     db->ids.assign((size_t)capacity, -1); db->counts.assign((size_t)capacity, 0);
     if (stream) db->stream = (hipStream_t)stream;
     else {
-        hipError_t e = hipStreamCreate(&db->stream);
+        hipError_t e = create_stream(&db->stream);
         if (e != hipSuccess) { delete db; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
         db->owns_stream = true;
     }
     hipError_t e = hipMalloc(&db->d_desc, (size_t)capacity * rows * 32);
     if (e == hipSuccess) e = hipMalloc(&db->d_counts, sizeof(int) * (size_t)capacity);
     if (e == hipSuccess) e = hipMalloc(&db->d_good, sizeof(int) * (size_t)capacity);
-    if (e == hipSuccess) e = hipMemset(db->d_counts, 0, sizeof(int) * (size_t)capacity);
+    if (e == hipSuccess) e = memset_on(db->stream, db->d_counts, 0, sizeof(int) * (size_t)capacity);
     if (e != hipSuccess) { aria_kfdb_destroy(db); return hip_fail(e, "aria_kfdb_create", __FILE__, __LINE__); }
     *out = db;
     return ARIA_OK;
@@ -1070,7 +1070,7 @@ int aria_kfdb_fetch(aria_kfdb_t db, int index, uint8_t* desc, int cap_rows, int*
     ARIA_HIP(hipSetDevice(db->device));
     if (n > 0) {
         if (!desc) return ARIA_E_INVALID;
-        ARIA_HIP(hipMemcpy(desc, db->d_desc + (size_t)slot * db->rows * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+        ARIA_HIP(memcpy_on(db->stream, desc, db->d_desc + (size_t)slot * db->rows * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
     }
     return ARIA_OK;
 }

@@ -159,7 +159,7 @@ int alloc_scratch(aria_orb_s* h) {
     rc = alloc_io(h, h->kp_cap);
     if (rc != ARIA_OK) return rc;
     ARIA_HIP(hipMalloc(&h->d_err_batch, 4 * sizeof(int)));
-    ARIA_HIP(hipMemset(h->d_err_batch, 0, 4 * sizeof(int)));
+    ARIA_HIP(memset_on(h->stream, h->d_err_batch, 0, 4 * sizeof(int)));
     h->plan_valid = false;
     return ARIA_OK;
 }
@@ -226,7 +226,7 @@ int alloc_io(aria_orb_s* h, int rows) {
     const size_t bytes = 64 + (size_t)rows * (sizeof(aria_keypoint) + 32);
     ARIA_HIP(hipMalloc(&h->d_out, bytes));
     ARIA_HIP(hipHostMalloc(&h->h_out, bytes));
-    ARIA_HIP(hipMemset(h->d_out, 0, 64));
+    ARIA_HIP(memset_on(h->stream, h->d_out, 0, 64));
     std::memset(h->h_out, 0, 64);
     h->d_count = reinterpret_cast<int*>(h->d_out);
     h->d_err_single = reinterpret_cast<int*>(h->d_out) + 4;
@@ -408,7 +408,7 @@ int aria_orb_create(const aria_orb_config* c, aria_orb_t* out) {
     if (c->stream) {
         h->stream = (hipStream_t)c->stream;
     } else {
-        hipError_t e = hipStreamCreate(&h->stream);
+        hipError_t e = create_stream(&h->stream);
         if (e != hipSuccess) { delete h; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
         h->owns_stream = true;
     }
@@ -547,8 +547,8 @@ int aria_orb_check(aria_orb_t h) {
     ARIA_HIP(hipSetDevice(h->device));
     ARIA_HIP(hipStreamSynchronize(h->stream));
     int two[4] = {0, 0, 0, 0};
-    ARIA_HIP(hipMemcpy(two, h->d_err_batch, 4 * sizeof(int), hipMemcpyDeviceToHost));
-    if (two[0] || two[1] || two[2]) ARIA_HIP(hipMemset(h->d_err_batch, 0, 4 * sizeof(int)));
+    ARIA_HIP(memcpy_on(h->stream, two, h->d_err_batch, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (two[0] || two[1] || two[2]) ARIA_HIP(memset_on(h->stream, h->d_err_batch, 0, 4 * sizeof(int)));
     h->rows_needed = two[2];
     note_slow_blocks(h, two[1]);
     return errbits_to_status(two[0]);
@@ -632,7 +632,7 @@ int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* hos
         // the batch path keeps blurred levels in Q4 order (orb_device.h): fetch the row quads, put the rows back in order
         const int hq = (g.h + 3) & ~3;
         std::vector<uint8_t> tmp((size_t)g.pitch * hq);
-        ARIA_HIP(hipMemcpy(tmp.data(), h->D.blur + g.blur_off, tmp.size(), hipMemcpyDeviceToHost));
+        ARIA_HIP(memcpy_on(h->stream, tmp.data(), h->D.blur + g.blur_off, tmp.size(), hipMemcpyDeviceToHost));
         for (int y = 0; y < g.h; y++)
             for (int x = 0; x < g.w; x++) host_out[(size_t)y * g.w + x] = tmp[(size_t)q4_offset(x, y, g.pitch)];
         return ARIA_OK;
@@ -640,7 +640,8 @@ int aria_orb_debug_read_level(aria_orb_t h, int level, int blurred, uint8_t* hos
     if (blurred) { src = h->D.blur + g.blur_off; spitch = (size_t)g.pitch; }
     else if (level == 0) { src = h->last_src.img; spitch = (size_t)h->last_src.row_stride; }
     else { src = h->D.raw + g.raw_off; spitch = (size_t)g.pitch; }
-    ARIA_HIP(hipMemcpy2D(host_out, (size_t)g.w, src, spitch, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost));
+    ARIA_HIP(hipMemcpy2DAsync(host_out, (size_t)g.w, src, spitch, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost, h->stream));
+    ARIA_HIP(hipStreamSynchronize(h->stream));
     return ARIA_OK;
 }
 

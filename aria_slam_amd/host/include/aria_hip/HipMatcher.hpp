@@ -54,6 +54,8 @@ public:
     void* streamArg() const { return stream_; }
     int device() const { return device_; }
     void reserve(int nq, int nt) { ensure(nq, nt); }       // creates / grows the C handle
+    // rows per set the handle accepts as it is; growing it (reserve, or a larger call) drops the resident set
+    bool fits(int nq, int nt) const { return m_ && nq <= cap_q_ && nt <= cap_t_; }
 
 private:
     void ensure(int nq, int nt);

@@ -1,6 +1,7 @@
 // See aria_hip/FrontEnd.hpp.
 #include "aria_hip/FrontEnd.hpp"
 
+#include <algorithm>
 #include <stdexcept>
 #include <utility>
 
@@ -74,7 +75,9 @@ void FrontEnd::extractAndMatch(const std::uint8_t* image_data, int width, int he
         }
         hm.retainDevice(nullptr, 0);
     }
-    if (have_prev && n > 0 && n_prev > 0 && hm.residentRows() == n_prev) {
+    // (a frame larger than the matcher handle was created for -- a tie storm, or setMaxFeatures raised mid-sequence -- makes
+    // the handle grow, which drops the resident set: such a frame takes the host port call below and becomes resident after)
+    if (have_prev && n > 0 && n_prev > 0 && hm.residentRows() == n_prev && hm.fits(std::max(n, n_prev), std::max(n, n_prev))) {
         if (cfg_.legacy_order) hm.matchDevice(nullptr, n_prev, dr.descriptors, n, result_.matches, cfg_.ratio_threshold);
         else hm.matchDevice(dr.descriptors, n, nullptr, n_prev, result_.matches, cfg_.ratio_threshold);
     } else if (have_prev && n > 0 && n_prev > 0) {

@@ -1,4 +1,5 @@
 // euroc_frontend <dataset_path> [max_features=2000] [--legacy-order] [--csv out.csv] [--loop] [--devices N] [--shards K]
+//                [--batch B] [--decode-threads T]
 //
 // The feature front-end of the reference's only end-to-end harness, src/euroc_eval.cpp:128-176, driven through the
 // ports instead of cv::cuda::ORB / cv::cuda::DescriptorMatcher: for every image of an ASL/EuRoC sequence
@@ -14,9 +15,16 @@
 // merged stream in frame order on device 0 afterwards (it is a sequential scan over the sequence by nature), so --loop
 // gives the same keyframes and loops for every K. K > N runs several logical shards on one device.
 //
+// --batch B (round 4): every shard runs the CHUNKED pipeline of aria_hip/BatchFrontEnd.hpp instead of one processFrame call
+// per image -- T decode workers fill pinned buffers, the copy stream uploads chunk c + 1 while the compute stream extracts
+// all B frames of chunk c in one batch pass and matches its B pairs in one launch (the kernels bench.py measures), results
+// come back per chunk. Same per-frame results (hashes, keyframes, loops) as the frame-at-a-time run; the summary names
+// decode, staging and kernel time apart. The loop-closure step then runs over the merged stream as in the sharded mode.
+//
 // Prints the progress line every 100 frames like the reference (:271-277) and a summary; --csv writes
 // "frame,timestamp,keypoints,matches,hash,keyframe,loop_match_id,loop_score" per frame, hash = FNV-1a 64 over the frame's
 // keypoint records, descriptor rows and match records (what the parity test compares with the oracle's).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -30,10 +38,12 @@
 #include <vector>
 
 #include "aria_hip/AslSequence.hpp"
+#include "aria_hip/BatchFrontEnd.hpp"
 #include "aria_hip/FrontEnd.hpp"
 #include "aria_hip/HipFactory.hpp"
 #include "aria_hip/HipLoopDetector.hpp"
 #include "aria_hip/Shard.hpp"
+#include "aria_orb_hip.h"
 
 using namespace aria;
 
@@ -63,10 +73,10 @@ std::uint64_t frame_hash(const core::Frame& f, const std::vector<core::Match>& m
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "Usage: %s <dataset_path> [max_features] [--legacy-order] [--csv file] [--loop] [--devices N] [--shards K]\n", argv[0]);
+        std::fprintf(stderr, "Usage: %s <dataset_path> [max_features] [--legacy-order] [--csv file] [--loop] [--devices N] [--shards K] [--batch B] [--decode-threads T]\n", argv[0]);
         return -1;                                                        // euroc_eval.cpp:64-70
     }
-    int max_features = 2000, devices = 1, shards = 0;
+    int max_features = 2000, devices = 1, shards = 0, batch = 0, decode_threads = 4;
     bool legacy = false, loop = false;
     std::string csv;
     for (int i = 2; i < argc; i++) {
@@ -75,10 +85,25 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) csv = argv[++i];
         else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--shards") && i + 1 < argc) shards = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--decode-threads") && i + 1 < argc) decode_threads = std::atoi(argv[++i]);
         else max_features = std::atoi(argv[i]);
     }
     if (devices < 1) devices = 1;
     if (shards < 1) shards = devices;
+    if (batch < 0) batch = 0;
+    if (decode_threads < 1) decode_threads = 1;
+    {
+        // --devices names HIP ordinals 0 .. N-1: refuse up front what the machine does not have (FactoryConfig::cuda_device,
+        // include/factory/PipelineFactory.hpp:24, is taken on trust by the reference)
+        int ndev = 0;
+        const int rc = aria_device_count(&ndev);
+        if (rc != ARIA_OK || ndev < devices) {
+            std::fprintf(stderr, "--devices %d: %d HIP device%s present%s%s\n", devices, ndev, ndev == 1 ? "" : "s",
+                         rc != ARIA_OK ? ": " : "", rc != ARIA_OK ? aria_status_string(rc) : "");
+            return -1;
+        }
+    }
     io::AslSequence seq;
     if (!seq.load(argv[1])) {
         std::fprintf(stderr, "Failed to load dataset from %s\n", argv[1]);
@@ -93,17 +118,39 @@ int main(int argc, char** argv) {
     std::atomic<std::size_t> done{0};
     int w = 0, h = 0;
     const bool sharded = shards > 1;
+    const bool posthoc_loop = loop && (sharded || batch > 0);      // the loop step over the merged stream, after the shards
+    std::vector<pipeline::BatchStats> bstats((size_t)shards);
     const auto t0 = std::chrono::steady_clock::now();
 
     // one shard = one FrontEnd (its own extractor + matcher handles on its device) over frames [first, hi)
     auto run_shard = [&](int s) {
         try {
             const pipeline::ShardPlan sp = pipeline::shardPlan(N, s, shards);
+            if (batch > 0) {
+                pipeline::BatchFrontEndConfig bc;
+                bc.hip_device = s % devices;
+                bc.max_features = max_features;
+                bc.chunk = batch;
+                bc.decode_threads = decode_threads;
+                bc.legacy_order = legacy;
+                pipeline::BatchFrontEnd bfe(bc);
+                bfe.run(seq, sp.first, sp.lo, sp.hi, [&](std::size_t i, const core::Frame& f, const std::vector<core::Match>& m) {
+                    FrameRecord& o = rec[i];
+                    o.keypoints = f.numKeypoints();
+                    o.matches = m.size();
+                    o.hash = frame_hash(f, m);
+                    if (posthoc_loop) o.frame = std::make_unique<core::Frame>(f);
+                    ++done;
+                });
+                bstats[(size_t)s] = bfe.stats();
+                if (s == 0) { w = bfe.width(); h = bfe.height(); }
+                return;
+            }
             factory::HipFactoryConfig fc;                                 // PipelineFactory's HIP mode (aria_hip/HipFactory.hpp)
             fc.hip_device = s % devices;
             fc.max_features = max_features;
             fc.frontend.legacy_order = legacy;
-            fc.enable_loop_closure = loop && !sharded;                    // LoopClosureDetector(200, 0.4, 50), euroc_eval.cpp:103
+            fc.enable_loop_closure = loop && !posthoc_loop;               // LoopClosureDetector(200, 0.4, 50), euroc_eval.cpp:103
             std::unique_ptr<pipeline::FrontEnd> fe = factory::createHip(fc);
             std::vector<std::uint8_t> gray;
             int fw = 0, fh = 0;
@@ -118,7 +165,7 @@ int main(int argc, char** argv) {
                 o.hash = frame_hash(*r.frame, r.matches);
                 o.is_keyframe = r.is_keyframe;
                 if (r.loop) { o.loop_match_id = (long long)r.loop->match_id; o.loop_score = r.loop->score; }
-                if (loop && sharded) o.frame = std::make_unique<core::Frame>(*r.frame);
+                if (posthoc_loop) o.frame = std::make_unique<core::Frame>(*r.frame);
                 const std::size_t d = ++done;
                 if (s == 0) { w = fw; h = fh; }
                 if (!sharded && d % 100 == 0) {                            // euroc_eval.cpp:271-277
@@ -143,8 +190,8 @@ int main(int argc, char** argv) {
         if (!errors[(size_t)s].empty()) { std::fprintf(stderr, "shard %d: %s\n", s, errors[(size_t)s].c_str()); return 1; }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-    // the loop-closure step of a sharded run: the merged stream, in frame order (euroc_eval.cpp:230-247)
-    if (loop && sharded && N > 0) {
+    // the loop-closure step of a sharded or batched run: the merged stream, in frame order (euroc_eval.cpp:230-247)
+    if (posthoc_loop && N > 0) {
         factory::HipFactoryConfig fc;
         fc.max_features = max_features;
         adapters::hip::HipLoopDetector ld(fc.loop_min_frames_between, fc.loop_min_score, fc.loop_min_matches,
@@ -180,6 +227,20 @@ int main(int argc, char** argv) {
     std::printf("frames %zu size %dx%d mean_keypoints %.2f mean_matches %.2f fps %.1f (PNG decode + H2D + extract + match + D2H; %d shard%s on %d device%s)\n",
                 N, w, h, N ? (double)total_kp / N : 0.0, N > 1 ? (double)total_matches / (N - 1) : 0.0, N / secs, shards,
                 shards > 1 ? "s" : "", devices, devices > 1 ? "s" : "");
+    if (batch > 0) {
+        pipeline::BatchStats t;
+        for (const pipeline::BatchStats& b : bstats) {
+            t.frames += b.frames; t.chunks += b.chunks; t.decode_s += b.decode_s; t.h2d_s += b.h2d_s; t.h2d_bytes += b.h2d_bytes;
+            t.gpu_s += b.gpu_s; t.d2h_s += b.d2h_s; t.d2h_bytes += b.d2h_bytes; t.deliver_s += b.deliver_s; t.wall_s = std::max(t.wall_s, b.wall_s);
+        }
+        // stage times are summed over shards and chunks; the stages overlap (decode of chunk c + 1 and its upload run beside
+        // the kernels of chunk c), so they do not add up to the wall time
+        std::printf("batch %d frames/chunk, %zu chunks, %d decode threads/shard | decode %.3f s (%.0f frames/s) | H2D %.3f s (%.2f GB/s) | "
+                    "extract+match kernels %.3f s (%.0f frames/s) | D2H %.3f s (%.2f GB/s) | deliver %.3f s | wall %.3f s\n",
+                    batch, t.chunks, decode_threads, t.decode_s, t.decode_s > 0 ? t.frames / t.decode_s : 0.0, t.h2d_s,
+                    t.h2d_s > 0 ? t.h2d_bytes / t.h2d_s * 1e-9 : 0.0, t.gpu_s, t.gpu_s > 0 ? t.frames / t.gpu_s : 0.0, t.d2h_s,
+                    t.d2h_s > 0 ? t.d2h_bytes / t.d2h_s * 1e-9 : 0.0, t.deliver_s, t.wall_s);
+    }
     if (loop) std::printf("keyframes %lld loops %lld\n", n_keyframes, n_loops);
     return 0;
 }

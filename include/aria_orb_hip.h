@@ -26,13 +26,14 @@
 #ifndef ARIA_ORB_HIP_H
 #define ARIA_ORB_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ARIA_ORB_HIP_ABI_VERSION 3
+#define ARIA_ORB_HIP_ABI_VERSION 4
 
 typedef enum {
     ARIA_OK = 0,
@@ -335,6 +336,31 @@ int   aria_matcher_sync(aria_matcher_t m);
  * which orders the two handles' work (needed by aria_matcher_match_device_async). Destroy it after the handles. */
 int aria_stream_create(int device, void** stream);
 int aria_stream_destroy(int device, void* stream);
+
+/* ---- device memory, staging copies and events (ABI 4) for a host that drives the BATCH entry points from the reference's
+ * language without linking the HIP runtime (aria_slam_amd/host BatchFrontEnd, euroc_frontend --batch). What the reference
+ * does through cv::cuda::GpuMat / the CUDA runtime on this path: device allocation + upload per frame
+ * (src/legacy/Frame.cpp:19, src/adapters/gpu/OrbCudaExtractor.cpp:83, :158 upload on the stream), download of the results
+ * (OrbCudaExtractor.cpp:102-103, :186-187), cudaStreamSynchronize (src/euroc_eval.cpp:153-154). Plain pointers and sizes;
+ * every call returns an aria_status (HIP failures as ARIA_E_HIP with the text in aria_last_hip_error()).
+ * Pinned host memory is what makes the copies asynchronous (a pageable source is staged by the runtime, synchronously).
+ * Events order two streams (the copy stream fills chunk c + 1 while the compute stream works on chunk c) and time them. */
+int aria_device_count(int* n);
+int aria_device_alloc(int device, size_t bytes, void** d_ptr);
+int aria_device_free(int device, void* d_ptr);
+int aria_host_alloc_pinned(size_t bytes, void** h_ptr);
+int aria_host_free_pinned(void* h_ptr);
+int aria_copy_h2d_async(int device, void* stream, void* d_dst, const void* h_src, size_t bytes);
+int aria_copy_d2h_async(int device, void* stream, void* h_dst, const void* d_src, size_t bytes);
+int aria_copy_d2d_async(int device, void* stream, void* d_dst, const void* d_src, size_t bytes);
+int aria_fill_async(int device, void* stream, void* d_dst, int byte_value, size_t bytes);
+int aria_stream_synchronize(int device, void* stream);
+int aria_event_create(int device, void** event);
+int aria_event_destroy(int device, void* event);
+int aria_event_record(int device, void* event, void* stream);
+int aria_stream_wait_event(int device, void* stream, void* event);
+int aria_event_synchronize(int device, void* event);
+int aria_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
 
 /* ---- synthetic workload: integer-only generator, identical bytes everywhere ------------ */
 int aria_synth_frame_pair(uint64_t seed, int width, int height, uint8_t* frame_a, uint8_t* frame_b);

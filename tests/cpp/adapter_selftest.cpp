@@ -242,6 +242,27 @@ int main(int argc, char** argv) {
             std::printf("\n");
         }
     }
+    // setMaxFeatures raised above the matcher handle's capacity (4096 rows) in the middle of a sequence. The
+    // larger frame makes the matcher grow, which drops its resident set: FrontEnd must take the host port call for that
+    // frame instead of throwing, and be back on the device hand-off afterwards. All three modes give the same matches.
+    for (int mode = 0; mode < 3; mode++) {
+        factory::HipFactoryConfig fc;
+        fc.max_features = 2000;
+        fc.enable_loop_closure = false;
+        fc.frontend.device_handoff = mode != 0;
+        std::unique_ptr<pipeline::FrontEnd> fe;
+        if (mode == 2) fe = factory::createHip(fc);
+        else fe = std::make_unique<pipeline::FrontEnd>(std::make_unique<adapters::hip::OrbHipExtractor>(2000),
+                                                       std::make_unique<adapters::hip::HipMatcher>(), fc.frontend);
+        std::printf("fe_grow_%d", mode);
+        const uint8_t* seq[4] = {a.data(), b.data(), a.data(), b.data()};
+        for (int i = 0; i < 4; i++) {
+            if (i == 1) fe->extractor().setMaxFeatures(6000);
+            const auto& r = fe->processFrame(seq[i], W, H, 0.05 * i);
+            std::printf(" %zu:%zu:%016llx", r.frame->numKeypoints(), r.matches.size(), fnv(r.matches.data(), r.matches.size() * sizeof(core::Match)));
+        }
+        std::printf("\n");
+    }
     std::printf("DONE\n");
     return 0;
 }

@@ -113,5 +113,17 @@ def test_adapters_equal_python_binding_and_reference_conventions(aria, selftest)
             w = O2.match_ratio(prev["descriptors"], cur["descriptors"], 0.75) if legacy else O2.match_ratio(cur["descriptors"], prev["descriptors"], 0.75)
             exp.append("%d:%s" % (len(w), _fnv(w.tobytes())))
         assert rows[0][2:] == exp
+    # setMaxFeatures(6000) after the first frame (above the matcher handle's 4096 rows): no throw, same matches in every mode,
+    # and they are the oracle's for (2000-feature a) -> (6000-feature b, a, b)
+    grow = [kv["fe_grow_%d" % mode] for mode in range(3)]
+    assert grow[0] == grow[1] == grow[2], grow
+    e.setMaxFeatures(6000)
+    fa6, fb6 = e.extract(a), e.extract(b)
+    assert len(fb6["keypoints"]) > 4096
+    exp = ["%d:0:%s" % (len(fa2["keypoints"]), _fnv(b""))]
+    for cur, prev in ((fb6, fa2), (fa6, fb6), (fb6, fa6)):
+        w = O2.match_ratio(cur["descriptors"], prev["descriptors"], 0.75)
+        exp.append("%d:%d:%s" % (len(cur["keypoints"]), len(w), _fnv(w.tobytes())))
+    assert grow[0] == exp
     e.close()
     m.close()

@@ -260,3 +260,52 @@ def test_euroc_frontend_shards_equal_the_single_shard_run(aria, hostlib, tmp_pat
     assert runs["k5"] == runs["one"]
     assert sum(int(r.split(",")[5]) for r in runs["one"][1:]) > 50          # keyframes exist, so the loop step did run
     assert any(int(r.split(",")[6]) >= 0 for r in runs["one"][1:])          # ... and found the loop
+
+
+@pytest.mark.gpu
+def test_euroc_frontend_batch_mode_equals_the_frame_at_a_time_run(aria, hostlib, tmp_path):
+    """euroc_frontend --batch B: chunks of B frames through aria_orb_extract_batch_device +
+    aria_matcher_match_batch_device (decode workers -> pinned ring -> copy stream -> batch kernels -> result stream), the
+    descriptors of a chunk's last frame carried to the next chunk on the device. BASELINE.json configs[0] size: 752x480,
+    1000 kp. Every CSV row (counts, hash over keypoint records + descriptor rows + match records, keyframe flag, loop id and
+    score) must equal the frame-at-a-time run's -- for one shard and three, for a chunk size that does not divide the
+    sequence, for chunks of one frame, and in the legacy query/train order."""
+    seq, _ = _make_dataset(aria, str(tmp_path), 19, w=752, h=480, revisit=3)          # 41 frames
+    exe = os.path.join(PKG, "euroc_frontend")
+
+    def run(name, extra):
+        csv = os.path.join(str(tmp_path), name + ".csv")
+        out = subprocess.run([exe, str(tmp_path), "1000", "--csv", csv, "--loop"] + extra, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return open(csv).read().strip().split("\n"), out.stdout
+
+    one, _ = run("one", [])
+    assert len(one) == len(seq) + 1
+    for name, extra in (("b16", ["--batch", "16"]), ("b16k3", ["--batch", "16", "--shards", "3", "--decode-threads", "2"]),
+                        ("b7", ["--batch", "7"]), ("b1", ["--batch", "1"]), ("b64", ["--batch", "64"])):
+        got, stdout = run(name, extra)
+        assert got == one, name
+        assert "extract+match kernels" in stdout and "decode" in stdout and "H2D" in stdout, stdout
+    legacy, _ = run("legacy", ["--legacy-order"])
+    got, _ = run("legacy_b16", ["--legacy-order", "--batch", "16", "--shards", "2"])
+    assert got == legacy and legacy != one
+    assert sum(int(r.split(",")[3]) for r in one[1:]) > 1000                       # the pairs do match
+
+
+def test_runtime_helpers_fail_loudly_without_a_device(aria):
+    """ABI 4 (device memory, staging copies, events): exported, and on a machine without a GPU they report
+    ARIA_E_NO_DEVICE / ARIA_E_HIP instead of pretending -- the batched C++ driver has no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = aria.load_library()
+    n = C.c_int(-1)
+    assert L.aria_device_count(C.byref(n)) == 0 and n.value == 0
+    p = C.c_void_p()
+    assert L.aria_device_alloc(0, C.c_size_t(1024), C.byref(p)) != 0 and not p.value
+    assert L.aria_host_alloc_pinned(C.c_size_t(1024), C.byref(p)) != 0 and not p.value
+    assert L.aria_event_create(0, C.byref(p)) != 0 and not p.value
+    exe = os.path.join(PKG, "euroc_frontend")
+    if os.path.exists(exe):
+        out = subprocess.run([exe, "/nonexistent", "--batch", "8"], capture_output=True, text=True, timeout=60)
+        assert out.returncode != 0 and "HIP device" in out.stderr

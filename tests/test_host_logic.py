@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(aria):
     for name in declared:
         assert hasattr(L, name), "libaria_orb_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared, "python binding list and header disagree"
-    assert aria.abi_version() == 3
+    assert aria.abi_version() == 4
 
 
 def test_status_strings(aria):
