@@ -41,7 +41,7 @@ EXPORTS = [
     "aria_device_count", "aria_device_alloc", "aria_device_free", "aria_host_alloc_pinned", "aria_host_free_pinned",
     "aria_copy_h2d_async", "aria_copy_d2h_async", "aria_copy_d2d_async", "aria_fill_async", "aria_stream_synchronize",
     "aria_event_create", "aria_event_destroy", "aria_event_record", "aria_stream_wait_event", "aria_event_synchronize",
-    "aria_event_elapsed_ms",
+    "aria_event_elapsed_ms", "aria_matcher_knn_kernel",
 ]
 
 
@@ -156,6 +156,8 @@ def load_library():
                                      C.c_int, C.POINTER(C.c_int)]
     L.aria_orb_fast_blur_kernel.argtypes = [C.c_void_p]
     L.aria_orb_fast_blur_kernel.restype = C.c_char_p
+    L.aria_matcher_knn_kernel.argtypes = [C.c_void_p]
+    L.aria_matcher_knn_kernel.restype = C.c_char_p
     L.aria_orb_last_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.aria_matcher_match_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,

@@ -500,10 +500,10 @@ void launch_one_fp4(int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, c
 
 }  // namespace
 
-void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
-                      const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
-                      uint2* keys, int maxq, double ratio, int* good, int max_train, int* gate) {
-    if (nq_max <= 0 || n_pairs <= 0) return;
+const char* launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
+                             const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
+                             uint2* keys, int maxq, double ratio, int* good, int max_train, int* gate) {
+    if (nq_max <= 0 || n_pairs <= 0) return "";
     static const int force_nc = [] { const char* e = aria_getenv("ARIA_KNN_NC"); return e ? atoi(e) : 0; }();
     // variants build: ARIA_KNN_IMPL=int8 keeps the int8 kernel for every train-set size (the product takes the FP4 path up to 4096)
     static const bool force_i8 = [] { const char* e = aria_getenv("ARIA_KNN_IMPL"); return e && e[0] == 'i'; }();
@@ -525,7 +525,7 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
             launch_one_fp4<1, kFp4Nc, kFp4Tt>(ARIA_KNN_ARGS, 0, 1, gate, 0);
             launch_one<1, true, 2, 64>(ARIA_KNN_ARGS, 0, 1, gate, 1);
         }
-        return;
+        return "k_knn2_fp4|k_knn2_mfma";
     }
     if (mode == 0) {
         if (wide) launch_one<0, true, 2, 64>(ARIA_KNN_ARGS);
@@ -539,6 +539,7 @@ void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const u
         else launch_one_fp4<1, 2, 64>(ARIA_KNN_ARGS);
     }
 #undef ARIA_KNN_ARGS
+    return (wide || force_i8) ? "k_knn2_mfma" : "k_knn2_fp4";
 }
 
 int knn2_split_count(int nq, int nt) {

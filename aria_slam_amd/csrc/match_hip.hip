@@ -282,6 +282,7 @@ struct aria_matcher_s {
     bool owns_stream = false;
     int max_query = 0, max_train = 0;
     bool knn_valu = false;          // ARIA_KNN_IMPL=valu: the vector-ALU kernel below instead of the matrix-core one
+    const char* last_knn = "";      // kernel form of the most recent batch / database kNN-2 launch (aria_matcher_knn_kernel)
     uint2* d_keys = nullptr;        // grow-only scratch: [n_pairs][maxq]
     size_t keys_cap = 0;
     int* d_err = nullptr;
@@ -368,14 +369,15 @@ void launch_knn2(aria_matcher_s* m, int mode, int nq_max, int n_pairs, const uin
                  const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride, uint2* keys,
                  int maxq, double ratio, int* good, int max_train) {
 #ifndef ARIA_VARIANTS
-    launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
-                     keys, maxq, ratio, good, max_train, m->d_err + 1);
+    m->last_knn = launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
+                                   keys, maxq, ratio, good, max_train, m->d_err + 1);
 #else
     if (!m->knn_valu) {
-        launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
-                         keys, maxq, ratio, good, max_train, m->d_err + 1);
+        m->last_knn = launch_knn2_mfma(mode, nq_max, n_pairs, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride, t_stride,
+                                       keys, maxq, ratio, good, max_train, m->d_err + 1);
         return;
     }
+    m->last_knn = "k_knn2 (vector ALU)";
     const dim3 grid((unsigned)((nq_max + 255) / 256), (unsigned)n_pairs);
     if (mode == 0)
         hipLaunchKernelGGL(k_knn2<0>, grid, dim3(256), 0, m->stream, q, nq_arr, nq_fixed, t, nt_arr, nt_fixed, q_stride,
@@ -526,6 +528,8 @@ int aria_stream_destroy(int device, void* stream) {
     ARIA_HIP(hipStreamDestroy((hipStream_t)stream));
     return ARIA_OK;
 }
+
+const char* aria_matcher_knn_kernel(aria_matcher_t m) { return m ? m->last_knn : ""; }
 
 int aria_matcher_set_profiling(aria_matcher_t m, int enable) {
     if (!m) return ARIA_E_INVALID;

@@ -9,8 +9,10 @@ namespace aria {
 // Matrix-core kNN-2 (knn2_mfma.hip). Same contract as k_knn2<MODE> in match_hip.hip, for n_pairs pairs of at most
 // nq_max queries: mode 0 stores (best, runner-up) keys (distance << 16 | train index, 0xFFFFFFFF = none) per query,
 // mode 1 counts the queries passing the double-precision ratio test into good[pair]. max_train = upper bound of
-// every pair's train count (selects the key layout).
-void launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
+// every pair's train count (selects the key layout). Returns the name of the kernel form it launched ("k_knn2_fp4",
+// "k_knn2_mfma", or "k_knn2_fp4|k_knn2_mfma" when both layouts were launched behind the device-side gate: the FP4 one does
+// the batch unless a pair's train count exceeds 4096), for aria_matcher_knn_kernel.
+const char* launch_knn2_mfma(int mode, int nq_max, int n_pairs, hipStream_t st, const uint8_t* q, const int* nq_arr, int nq_fixed,
                       const uint8_t* t, const int* nt_arr, int nt_fixed, int64_t q_stride, int64_t t_stride,
                       uint2* keys, int maxq, double ratio, int* good, int max_train, int* gate = nullptr);
 

@@ -309,6 +309,10 @@ class HipMatcher:
     def sync(self):
         check(self._L.aria_matcher_sync(self._h), "aria_matcher_sync")
 
+    def knn_kernel(self):
+        """Kernel form of the handle's most recent batch / database kNN-2 launch (aria_matcher_knn_kernel)."""
+        return self._L.aria_matcher_knn_kernel(self._h).decode()
+
     STAGES = ("knn2", "ratio_compact")
 
     def set_profiling(self, enable, stages=None):

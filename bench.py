@@ -50,15 +50,30 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("ARIA_CPU_BASELINE_THREADS", "16"))))
 
 
+KERNEL_SOURCES = {"k_fast_blur_stream": "fast_blur_stream.hip", "k_fast_blur_band": "fast_blur_band.hip"}
+
+
+def kernel_source_sha256(kernel):
+    """sha256 of the source file of the FAST/blur kernel (what tools/pmc_traffic.py stores next to its counters)."""
+    import hashlib
+    f = os.path.join(ROOT, "aria_slam_amd", "csrc", KERNEL_SOURCES.get(kernel, ""))
+    return hashlib.sha256(open(f, "rb").read()).hexdigest() if os.path.isfile(f) else None
+
+
 def load_traffic(chunk, kernel="k_fast_blur_band"):
-    """HBM bytes per frame of the FAST/blur kernel from the committed PMC passes (tools/pmc_traffic.sh), or None."""
-    for name in ("pmc_traffic_r3.json", "pmc_traffic_%d.json" % chunk, "pmc_traffic_1024.json"):
+    """HBM bytes per frame of the FAST/blur kernel from the committed PMC passes (tools/pmc_traffic.sh), the file's name,
+    and whether the file was measured on ANOTHER build of the kernel (its stored source hash differs from the tree's, or it
+    stores none): a constant read from profiles/, not a measurement of this run -- `traffic_stale` says when not to trust it."""
+    for name in ("pmc_traffic_r4.json", "pmc_traffic_r3.json", "pmc_traffic_%d.json" % chunk, "pmc_traffic_1024.json"):
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
-            k = json.load(open(f))["kernels"].get(kernel)
+            j = json.load(open(f))
+            k = j["kernels"].get(kernel)
             if k:
-                return k["fetch_bytes_per_frame"] + k["write_bytes_per_frame"], name
-    return None, None
+                have = (j.get("kernel_source_sha256") or {}).get(kernel)
+                stale = have is None or have != kernel_source_sha256(kernel)
+                return k["fetch_bytes_per_frame"] + k["write_bytes_per_frame"], name, stale
+    return None, None, None
 
 
 def cpu_baseline(width, height, nfeatures, budget_s=12.0):
@@ -331,27 +346,106 @@ def loop_closure_leg(A, torch, dist, dev, mat, last, B, cap, rank, world, rehear
         f = min(k * stride, B - 1)
         db.add(lo_frame + f, last["desc"][f], int(counts_host[f]))
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
+    gather_s = None
     if dist is not None:
-        g = db.all_gather(via_host=rehearsal)
+        db.all_gather(via_host=rehearsal)          # warm-up: the first collective of a size pays RCCL's channel setup
         torch.cuda.synchronize(dev)
+        times = []
+        for _ in range(3):
+            dist.barrier()
+            t0 = time.perf_counter()
+            g = db.all_gather(via_host=rehearsal)
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0)
+        gather_s = sorted(times)
     else:
         g = db
-    t1 = time.perf_counter()
+    t_scan0 = time.perf_counter()
     q = B - 1
     cands = g.find_candidates(mat, last["desc"][q], int(counts_host[q]), lo_frame + q, 200, 0.7)
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
+    scan_s = t2 - t_scan0
     ids = g.ids.cpu().numpy()
     out = {"keyframes": int((g.counts > 0).sum().item()), "slot_rows": cap, "db_bytes": int(g.desc.numel()),
-           "allgather_ms": round(1e3 * (t1 - t0), 3) if dist is not None else None,
+           "allgather_ms": round(1e3 * gather_s[1], 3) if gather_s else None,
+           "allgather_ms_all": [round(1e3 * t, 3) for t in gather_s] if gather_s else None,
            "allgather_backend": (None if dist is None else ("gloo via host (rehearsal)" if rehearsal else "nccl (RCCL)")),
-           "scan_ms": round(1e3 * (t2 - t1), 3),
+           "scan_ms": round(1e3 * scan_s, 3),
            "query_frame": int(lo_frame + q),
            "candidates": [[int(ids[i]), round(float(s), 6)] for i, s in cands]}
-    if dist is not None and not rehearsal:
-        out["allgather_GBs"] = round(g.desc.numel() * (world - 1) / world / max(t1 - t0, 1e-9) / 1e9, 2)
+    if dist is not None:
+        # bytes each rank RECEIVES (world - 1 slices of the padded database) over the median time, against the one-shot bound of
+        # on a fully connected xGMI node every peer pushes its slice over its own link (~153 GB/s each), so a
+        # rank can take in (world - 1) x 153 GB/s; a ring would be bound by ONE link. Reported, not asserted (message sizes of a
+        # few MB per rank are latency-dominated).
+        recv = g.desc.numel() * (world - 1) / world
+        out["allgather_GBs"] = round(recv / max(gather_s[1], 1e-9) / 1e9, 2)
+        out["allgather_slice_bytes"] = int(g.desc.numel() // world)
+        out["xgmi_one_shot_bound_GBs"] = round(153.0 * (world - 1), 1)
+        out["allgather_frac_of_bound"] = round(out["allgather_GBs"] / max(out["xgmi_one_shot_bound_GBs"], 1e-9), 4)
+        if rehearsal:
+            out["allgather_note"] = "rehearsal: gloo through host memory on one GPU -- not an xGMI measurement"
     return out
+
+
+def streamed_leg(torch, dev, ext, mat, host_pinned, B, W, H, cap, sets, last, se, sm, args, halo_desc, halo_cnt, chunk_frames=1024):
+    """h2d_staging.streamed_*: one step whose frames are NOT resident -- the shard comes from pinned host memory in chunks of
+    `chunk_frames` on a copy stream (two device buffers: chunk c + 1 is copied while chunk c is extracted), the matcher runs
+    on its stream once the last chunk is described. Untimed by `value`; run three times, the median is reported. The results
+    must equal the resident step's (same frames)."""
+    C = min(chunk_frames, B)
+    sc = torch.cuda.Stream(device=dev)
+    bufs = [torch.empty((C, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+    d = sets[0] if (len(sets) == 1 or sets[0] is not last) else sets[1]
+    dstride = cap * 32
+
+    def run():
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for c, lo in enumerate(range(0, B, C)):
+            n, s = min(C, B - lo), c & 1
+            with torch.cuda.stream(sc):
+                if c >= 2:
+                    sc.wait_event(free[s])
+                bufs[s][:n].copy_(host_pinned[lo:lo + n], non_blocking=True)
+                ready[s].record(sc)
+            with torch.cuda.stream(se):
+                se.wait_event(ready[s])
+                ext.extract_batch_device(bufs[s].data_ptr(), n, W, H, d["kps"].data_ptr() + lo * cap * 24,
+                                         d["desc"].data_ptr() + lo * cap * 32, d["counts"].data_ptr() + 4 * lo, cap)
+                free[s].record(se)
+        done = torch.cuda.Event()
+        done.record(se)
+        with torch.cuda.stream(sm):
+            sm.wait_event(done)
+            mat.match_batch_device(d["desc"], d["counts"], halo_desc, halo_cnt, 1, dstride, args.ratio, d["matches"], d["nmatches"], cap)
+            mat.match_batch_device(d["desc"].data_ptr() + dstride, d["counts"].data_ptr() + 4, d["desc"], d["counts"], B - 1,
+                                   dstride, args.ratio, d["matches"].data_ptr() + cap * 12, d["nmatches"].data_ptr() + 4, cap)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    run()                                           # warm-up (buffers touched, streams created)
+    ts = sorted(run() for _ in range(3))
+    ext.check()
+    mat.sync()
+    same = None
+    if d is not last:
+        nl = last["counts"].cpu().numpy()
+        same = bool(torch.equal(d["counts"], last["counts"]) and torch.equal(d["nmatches"], last["nmatches"]))
+        if same:                                     # rows beyond a frame's count are undefined: compare the defined ones
+            import numpy as _np
+            idx = _np.linspace(0, B - 1, 64).astype(int)
+            for f in idx:
+                n = int(nl[f])
+                same = same and bool(torch.equal(d["desc"][f, :n], last["desc"][f, :n])) and bool(torch.equal(d["kps"][f, :n], last["kps"][f, :n]))
+    return {"what": "one step with the frames streamed from pinned host memory in chunks on a copy stream beside the extraction "
+                    "(double-buffered), matcher behind the last chunk; median of 3 runs after a warm-up; never `value`",
+            "chunk_frames": C, "frames": B, "seconds": round(ts[1], 4), "frames_per_s": round(B / ts[1], 1),
+            "frames_per_s_all": [round(B / t, 1) for t in ts], "h2d_GBs_sustained": round(B * W * H / ts[1] / 1e9, 2),
+            "equals_resident_step": same}
 
 
 def main():
@@ -461,26 +555,32 @@ def main():
     host = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=False)
     A.synth_sequence(seed0, args.pairs, W, H, out=host.numpy())
     # H2D staging of the shard, reported separately and never part of `value`: the upload from
-    # pageable memory as a sequence reader would hold it, and once more from pinned memory (what a reader that decodes
-    # into registered buffers gets). Scaling is linear in the GPUs as long as these rates exceed the compute rate.
-    torch.cuda.synchronize(dev)
-    t_up = time.perf_counter()
-    images = host.to(dev)
-    torch.cuda.synchronize(dev)
-    t_up = time.perf_counter() - t_up
-    staging = {"bytes": int(host.numel()), "pageable_s": round(t_up, 4), "pageable_GBs": round(host.numel() / t_up / 1e9, 2)}
+    # pageable memory as a sequence reader would hold it, and from pinned memory (what a reader that decodes into registered
+    # buffers gets -- aria_slam_amd/host BatchFrontEnd does). Each figure is the MEDIAN of three copies after a warm-up copy
+    # (round 3 timed one cold copy per path: first-touch and registration cost, not a rate). Scaling is linear in the GPUs
+    # as long as these rates exceed the compute rate; the `streamed` leg further down feeds the extractor that way.
+    def timed_copy(dst, src, non_blocking):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        dst.copy_(src, non_blocking=non_blocking)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t
+
+    images = host.to(dev)                                   # warm-up copy: the shard becomes resident
+    t_page = sorted(timed_copy(images, host, False) for _ in range(3))
+    staging = {"bytes": int(host.numel()), "pageable_s": round(t_page[1], 4), "pageable_GBs": round(host.numel() / t_page[1] / 1e9, 2),
+               "pageable_GBs_all": [round(host.numel() / t / 1e9, 2) for t in t_page], "copies": "median of 3 after a warm-up copy"}
+    host_pinned = None
     try:
-        n_pin = min(B, 2048)
-        pinned = host[:n_pin].pin_memory()
-        torch.cuda.synchronize(dev)
-        t_pin = time.perf_counter()
-        images[:n_pin].copy_(pinned, non_blocking=True)
-        torch.cuda.synchronize(dev)
-        t_pin = time.perf_counter() - t_pin
-        staging.update({"pinned_sample_bytes": int(pinned.numel()), "pinned_GBs": round(pinned.numel() / t_pin / 1e9, 2)})
-        del pinned
+        host_pinned = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=True)
+        host_pinned.copy_(host)
+        timed_copy(images, host_pinned, True)               # warm-up
+        t_pin = sorted(timed_copy(images, host_pinned, True) for _ in range(3))
+        staging.update({"pinned_bytes": int(host_pinned.numel()), "pinned_GBs": round(host_pinned.numel() / t_pin[1] / 1e9, 2),
+                        "pinned_GBs_all": [round(host_pinned.numel() / t / 1e9, 2) for t in t_pin]})
     except RuntimeError as ex:          # pinning can be refused (memory limits): the pageable figure stands alone
         staging["pinned_error"] = str(ex)[:120]
+        host_pinned = None
     # halo frame (shard.shard_plan: the frame before this rank's range, recomputed rather than exchanged); rank 0 has
     # no predecessor and wraps around to its own last frame
     if rank > 0:
@@ -614,6 +714,8 @@ def main():
     for _ in range(args.steps):
         last = step()
     flush_pending()               # (the last step's matching runs alone in either schedule)
+    torch.cuda.synchronize(dev)
+    dt_local = time.perf_counter() - t0          # this rank's own clock: start barrier -> its last kernel done
     barrier()
     dt = time.perf_counter() - t0
     for e_ in exts:
@@ -642,6 +744,15 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         all_ok = bool(int(okt.item()))
 
+    # per-rank figures for the N > 1 line: a straggler rank must be visible when the curve is run
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([dt_local, 1.0 if (verification is None or verification["ok"]) else 0.0, float(B * args.steps)],
+                            dtype=torch.float64, device=("cpu" if rehearsal else dev))
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in t.cpu().tolist()] for t in allr]
+
     # ---- untimed: loop-closure exchange + scan (configs[4]) ----
     loop_closure = None
     if not args.no_loop_closure and args.steps > 0:
@@ -657,6 +768,15 @@ def main():
             single = single_frame_latency(A, dev, images, W, H, NF)
         except Exception as e:
             single = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- untimed: the shard fed from pinned host memory in chunks on a copy stream, beside the extraction ----
+    streamed = None
+    if host_pinned is not None and args.steps > 0 and lanes == 1:
+        try:
+            streamed = streamed_leg(torch, dev, ext, mat, host_pinned, B, W, H, cap, sets, last, se, sm, args, halo_desc, halo_cnt)
+        except Exception as e:
+            streamed = {"error": "%s: %s" % (type(e).__name__, e)}
+    del host_pinned
 
     # extra untimed step with every stage bracketed, extractor and matcher one after the other -> stage_us_per_frame
     ext.set_profiling(True)
@@ -696,7 +816,7 @@ def main():
         fb_bytes_per_launch = alg["fast_blur"] * frames_per_launch
         achieved = fb_bytes_per_launch / (fb_ms_per_launch * 1e-3) / 1e9 if fb_ms_per_launch > 0 else 0.0
         fb_kernel = ext.fast_blur_kernel()
-        traffic_pf, traffic_src = load_traffic(args.chunk, fb_kernel)
+        traffic_pf, traffic_src, traffic_stale = load_traffic(args.chunk, fb_kernel)
         ext_ms = sum(all_ms[k] for k in ("resize", "fast_blur", "select", "describe")) * (prof_frames / max(frames_all, 1))
         pair_ops = 512.0 * float(cnt_host[1:].astype(np.float64) @ cnt_host[:-1].astype(np.float64))   # 2 * 256 * sum(nq * nt)
         if stage_ms.get("knn2"):
@@ -705,12 +825,15 @@ def main():
             knn_ms, knn_steps, knn_src = all_ms["knn2"], 1, "extra untimed step (the timed region does not bracket the matcher's stream)"
         # train sets up to 4096 rows (every SLAM frame) run on the FP4 matrix path: one E2M1 value per descriptor bit,
         # v_mfma_f32_32x32x64_f8f6f4; peak = the dense FP4 figure of MI355X_MICROARCH.md (10 PFLOP/s, 2 x the int8 / fp8 one)
-        fp4 = int(cnt_host.max()) <= 4096
+        # which kernel did it is what the handle reports (aria_matcher_knn_kernel), not a guess from the counts: "a|b" = both
+        # layouts launched behind the device-side gate, the FP4 one ran unless a train set exceeded 4096 rows
+        knn_name = mat.knn_kernel()
+        fp4 = knn_name == "k_knn2_fp4" or (knn_name == "k_knn2_fp4|k_knn2_mfma" and int(cnt_host.max()) <= 4096)
         mpeak = 10000.0 if fp4 else 5000.0
         matcher_roofline = {"kernel": ("k_knn2_fp4 (v_mfma_f32_32x32x64_f8f6f4 on E2M1 bit operands + per-lane top-2)" if fp4 else
                                        "k_knn2_mfma (v_mfma_i32_32x32x32_i8 + per-lane top-2)"), "bound": "mfma",
                             "achieved": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12, 1) if knn_ms else None,
-                            "peak": mpeak, "unit": "TOP/s",
+                            "peak": mpeak, "unit": "TOP/s", "launched": knn_name,
                             "frac": round(pair_ops * knn_steps / (knn_ms * 1e-3) / 1e12 / mpeak, 4) if knn_ms else None,
                             "measured_in": knn_src,
                             # the matcher's HBM share is tiny (B_match = 32 (Nq + Nt) + 16 Nq per pair) and its
@@ -731,6 +854,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": (int(traffic_pf * frames_per_launch) if traffic_pf and (W, H, NF) == (640, 480, 2000) else None),
             "traffic_source": traffic_src,
+            # the PMC file is a committed measurement, not a counter read of this run: stale = it was taken on another
+            # build of the kernel's source file (tools/pmc_traffic.py stores the sha256 it measured)
+            "traffic_stale": traffic_stale,
             "algorithmic_bytes_per_launch": int(fb_bytes_per_launch),
             "avg_launch_ms": round(fb_ms_per_launch, 4), "frames_per_launch": frames_per_launch,
             "dominant_stage": dom,
@@ -782,6 +908,16 @@ def main():
                        "slow_path_blocks": int(slow_blocks)},
             "roofline": roofline,
         }
+        if per_rank is not None:
+            # per-rank view of the same timed region: own clock (start barrier -> own last kernel done), own verification
+            fps = [pr[2] / pr[0] for pr in per_rank]
+            out["ranks"] = {"frames_per_s": [round(x, 1) for x in fps], "seconds": [round(pr[0], 5) for pr in per_rank],
+                            "verified": [bool(pr[1] >= 0.5) for pr in per_rank],
+                            "min_frames_per_s": round(min(fps), 1), "max_frames_per_s": round(max(fps), 1),
+                            "slowest_rank": int(min(range(len(fps)), key=lambda i: fps[i])),
+                            "note": "value = all ranks' frames / the max-over-ranks barrier-to-barrier time; these are each rank's own clock"}
+            if not rehearsal:
+                assert rccl_ranks == world, "RCCL all-reduce saw %s ranks, world size %d" % (rccl_ranks, world)
         if rehearsal:
             out["rehearsal"] = True
             out["config"]["rehearsal_note"] = "all ranks share cuda:0, gloo collectives: the numbers are not a measurement"
@@ -793,6 +929,12 @@ def main():
         if single is not None:
             out["single_frame_host_path"] = single
         staging["frames_per_s_at_pageable_rate"] = round(staging["pageable_GBs"] * 1e9 / (W * H), 1)
+        if "pinned_GBs" in staging:
+            staging["frames_per_s_at_pinned_rate"] = round(staging["pinned_GBs"] * 1e9 / (W * H), 1)
+        if streamed is not None:
+            staging["streamed"] = streamed
+            if "frames_per_s" in streamed:
+                staging["streamed_frames_per_s"] = streamed["frames_per_s"]
         staging["note"] = ("upload of this rank's %d frames before the timed region; not part of `value`. The extractor "
                            "consumes %.1f GB/s of frames at the measured rate" % (B, out["value"] / max(n_gpus, 1) * W * H / 1e9))
         out["h2d_staging"] = staging

@@ -328,6 +328,11 @@ int  aria_kfdb_scan(aria_kfdb_t db, aria_matcher_t m, const uint8_t* query_desc,
 int aria_matcher_set_profiling(aria_matcher_t m, int enable);
 int aria_matcher_get_profile(aria_matcher_t m, int reset, double* stage_ms /*[2]*/, int64_t* stage_launches /*[2]*/,
                              int64_t* pairs);
+/* Diagnostics (like aria_orb_fast_blur_kernel): kernel form of the handle's most recent batch / database kNN-2 launch --
+ * "k_knn2_fp4" (FP4 matrix path, train sets <= 4096 rows), "k_knn2_mfma" (int8, wider train sets), or
+ * "k_knn2_fp4|k_knn2_mfma" when both were launched behind the device-side gate (the FP4 one does the batch unless some pair's
+ * train count exceeds 4096). bench.py keys the label and the peak of roofline.matcher on it. */
+const char* aria_matcher_knn_kernel(aria_matcher_t m);
 void* aria_matcher_stream(aria_matcher_t m);
 int   aria_matcher_sync(aria_matcher_t m);
 

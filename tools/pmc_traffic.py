@@ -46,6 +46,20 @@ def main():
         kf = factor4 if (k == "k_fast_blur_stream" and factor4) else factor
         out["kernels"][k] = {"fetch_bytes_per_frame_raw": round(fkb * 1024 / n), "fetch_bytes_per_frame": round(fkb * 1024 * kf / n),
                              "write_bytes_per_frame": round(wkb * 1024 / n), "fetch_factor": round(kf, 3)}
+    # the build these counters belong to: sha256 of the FAST/blur kernels' source files (bench.py prints traffic_stale when
+    # the tree's differ) and, where a checkout is present, HEAD
+    import hashlib
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out["kernel_source_sha256"] = {}
+    for k, f in (("k_fast_blur_stream", "fast_blur_stream.hip"), ("k_fast_blur_band", "fast_blur_band.hip")):
+        path = os.path.join(repo, "aria_slam_amd", "csrc", f)
+        if os.path.isfile(path):
+            out["kernel_source_sha256"][k] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    try:
+        out["git_head"] = subprocess.check_output(["git", "-C", repo, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        out["git_head"] = None          # the GPU box gets a snapshot without .git
     dst = os.path.join(root, "pmc_traffic_%d.json" % chunk)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
