@@ -118,6 +118,18 @@ __device__ __forceinline__ int ring_off(int y) { return ((y + 3) & (kRing - 1)) 
 #ifndef ARIA_COMPASS2
 #define ARIA_COMPASS2 1
 #endif
+// Rows per group of the wave's walk (the unroll factor of its loop). 7 = the window's height (round 3). 8 (round 4, measured
+// and NOT adopted): a group is then two whole row quads of the Q4-ordered blurred level, a lane collects the four dwords of
+// a quad in registers under STATIC indices and stores them with one 16-byte instruction (64 lanes x 16 contiguous bytes
+// instead of four instructions of 64 x 4 bytes at a 16-byte stride), and the per-group phases run once per 8 rows instead
+// of once per 7 -- 159 VGPRs, bit-identical (the 56 stream / parity tests), and no faster: 0.1992 / 0.2007 of the roofline
+// against 0.1995 / 0.2025 for 7 (A B A B, one box). Neither the store shape nor the per-group overhead is what bounds the
+// kernel; its vector-instruction count is (profiles/r4_mfma_blur_arithmetic.md).
+#ifndef ARIA_STREAM_G
+#define ARIA_STREAM_G 7
+#endif
+constexpr int kG = ARIA_STREAM_G;
+static_assert(kG == 7 || kG == 8, "the window holds 7 rows; 8 makes groups whole row quads");
 
 // fast_score.cpp cornerScore<16> for local pixel px of row `row` of the wave's raw ring: max over the 16 nine-arcs of
 // min(v - ring) and of min(ring - v), minus 1; both polarities ride in one register as a packed pair. The pixel is a
@@ -240,7 +252,9 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     const int w = A.w, h = A.h;
     // this wave's rows: blurred rows, candidates and pyramid source rows [r0, r1); ingest indices t_first .. t_last
     const int r0 = seg * A.seg_rows, r1 = min(h, r0 + A.seg_rows);
-    const int t_first = r0 == 0 ? -3 : r0 - 4, t_last = r1 == h ? h + 2 : r1 + 3;
+    // (kG == 8: the first group's first OUTPUT row t_first - 3 is a multiple of 4 -- r0 is -- so that every group is two whole
+    // row quads; the one or two extra rows above the segment cost a step each and feed no output)
+    const int t_first = kG == 8 ? r0 - 5 : (r0 == 0 ? -3 : r0 - 4), t_last = r1 == h ? h + 2 : r1 + 3;
     uint32_t* s_raw = reinterpret_cast<uint32_t*>(wl + kHdrBytes);                 // [kRing][64] dwords
     uint8_t* s_rawb = wl + kHdrBytes;
     uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
@@ -325,11 +339,11 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     uint32_t hprev[4] = {0u, 0u, 0u, 0u};
     int hprev_row = -1;
 
-    // ---- the 7-row register window; slot = (row + 3) % 7 (static after unrolling by 7) ----
-    uint32_t RC2[7][2], RE[7], RW[7];
-    float RF[7][4];
+    // ---- the 7-row register window in kG slots; slot = position of the row in its group (static after unrolling by kG) ----
+    uint32_t RC2[kG][2], RE[kG], RW[kG];
+    float RF[kG][4];
 #pragma unroll
-    for (int u = 0; u < 7; u++) {
+    for (int u = 0; u < kG; u++) {
         RC2[u][0] = RC2[u][1] = RE[u] = RW[u] = 0;
         RF[u][0] = RF[u][1] = RF[u][2] = RF[u][3] = 0.f;
     }
@@ -343,11 +357,11 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     // a load, so taking a row out of its register waits for EVERY vector-memory operation issued so far. At the top of a
     // group that meant waiting for the stores the pyramid step had issued a moment earlier (a full write round trip per
     // group); behind the scoring phase the youngest stores are the blurred rows of the walk, thousands of cycles old.
-    uint32_t pre[7], cur[7];
+    uint32_t pre[kG], cur[kG];
 #pragma unroll
-    for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t_first + u), in_off);
+    for (int u = 0; u < kG; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t_first + u), in_off);
 #pragma unroll
-    for (int u = 0; u < 7; u++) cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
+    for (int u = 0; u < kG; u++) cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
 
     // per-lane info for whoever processes a queue entry of this lane's pixels: x of px 0 | frame - frame0 | owner
     const uint32_t linfo = (uint32_t)(4 * max(R.gdw, 0)) | ((uint32_t)(R.frame - frame0) << 11) | (R.owner ? 1u << 31 : 0u);
@@ -434,28 +448,29 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         }
     };
 
-    const int G = (t_last - t_first + 1 + 6) / 7;
+    const int G = (t_last - t_first + 1 + kG - 1) / kG;
     // (loads past the last group are issued all the same, clamped to the last row: a condition around them would make the
     // compiler load into temporaries and copy -- i.e. wait -- at once)
 #pragma unroll
-    for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t_first + 7 + u), in_off);
+    for (int u = 0; u < kG; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t_first + kG + u), in_off);
     for (int gi = 0; gi < G; gi++) {
-        const int t0 = t_first + 7 * gi;
+        const int t0 = t_first + kG * gi;
         // ---- rows of this group into the ring; clear the score rows this group will fill ----
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
+        for (int u = 0; u < kG; u++) {
             s_raw[(((t0 + u + 3) & (kRing - 1)) << 6) + lane] = cur[u];
             s_mapw[(((t0 + u) & (kRing - 1)) << 6) + lane] = 0u;             // score row o = t - 3 (slot (o + 3) & 15)
         }
         wave_sync();
         // y-table window of the pyramid step: refilled here, a whole walk ahead of its first use
-        if (pyr && dy_next + 8 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn_h - 1)]; }
+        if (pyr && dy_next + kG + 2 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn_h - 1)]; }
         PHASE(0);
 
         // ---- the walk: row pass, column pass + store, compass reject ----
         uint32_t accw = 0;     // survivors of this group: step u, px j -> bit (j&1 ? 31 : 15) - (j>>1) - 2u
+        u32x4 qv = {0u, 0u, 0u, 0u};      // kG == 8: the four blurred dwords of the lane's row quad
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
+        for (int u = 0; u < kG; u++) {
             const int t = t0 + u;
             if (t <= t_last) {
                 // neighbours' dwords straight from their registers (DPP wave shifts): no LDS round trip in the walk. Lane 0's
@@ -477,9 +492,9 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 RF[u][0] = (float)rs0; RF[u][1] = (float)rs1; RF[u][2] = (float)rs2; RF[u][3] = (float)rs3;   // exact: < 2^16
 
                 const int o = t - 3;              // level row whose window [o-3, o+3] is now complete
-                // row o+d of the window lives in slot (u + 4 + d) % 7
-                const int sC = (u + 4) % 7, sM1 = (u + 3) % 7, sP1 = (u + 5) % 7, sM2 = (u + 2) % 7, sP2 = (u + 6) % 7,
-                          sM3 = (u + 1) % 7, sP3 = u;
+                // row o+d of the window lives in slot (u - 3 + d) mod kG
+                const int sC = (u + kG - 3) % kG, sM1 = (u + kG - 4) % kG, sP1 = (u + kG - 2) % kG, sM2 = (u + kG - 5) % kG,
+                          sP2 = (u + kG - 1) % kG, sM3 = (u + kG - 6) % kG, sP3 = u;
                 if (o >= r0 && o < r1) {
                     // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u). All values are
                     // integers * 2^-16 below 2^9, so the fp32 column pass is exact (a partial sum can only be inexact above
@@ -508,7 +523,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                     // needs a wave-uniform but run-time register index (groups are 7 rows, quads 4), which the compiler
                     // turns into four v_cndmask per row: 1.777 us; parking them in LDS under that index and storing 16 bytes
                     // per quad: +8 %; non-temporal stores: +35 % (the L2 no longer merges the rows of a line).
-                    if (R.owner) gstore_sv<uint32_t>(blur0 + (int64_t)(o >> 2) * (4 * A.blur_pitch) + ((o & 3) << 2), out_off, outw);
+                    if constexpr (kG == 8) qv[u & 3] = outw;
+                    else if (R.owner) gstore_sv<uint32_t>(blur0 + (int64_t)(o >> 2) * (4 * A.blur_pitch) + ((o & 3) << 2), out_off, outw);
+                } else if constexpr (kG == 8) {
+                    qv[u & 3] = 0u;           // rows outside the segment (or below the image, in the level's padded last quad)
                 }
                 if (o >= fy0 && o <= fy1) {
                     // compass reject, two pixels per packed-int16 op (see k_fast_blur_band): survive iff one of N, S AND one
@@ -535,6 +553,16 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #endif
                     }
                     accw |= (pass[0] | (pass[1] >> 1)) >> (2 * u);
+                }
+            } else if constexpr (kG == 8) {
+                qv[u & 3] = 0u;
+            }
+            if constexpr (kG == 8) {
+                // the quad's four rows are in: one 16-byte store per lane (Q4 order: 16 gdw inside row quad qo >> 2), as long as
+                // the quad belongs to this segment (segments are whole quads; the last quad of a level may reach below it)
+                if ((u & 3) == 3) {
+                    const int qo = t0 + u - 6;                       // first row of the quad: o - 3 of this step
+                    if (qo >= r0 && qo < r1 && R.owner) gstore_sv<u32x4>(blur0 + (int64_t)(qo >> 2) * (4 * A.blur_pitch), out_off, qv);
                 }
             }
         }
@@ -588,7 +616,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 
         // ---- 3x3 strict-max NMS + border filter for the rows whose lower neighbours are scored: rows <= o_lo + 5 (all of
         //      them in the last group). Candidates go to the frame's list through a wave-aggregated append. ----
-        const int nms_hi = gi + 1 < G ? min(o_lo + 5, fy1) : fy1;
+        const int nms_hi = gi + 1 < G ? min(o_lo + kG - 2, fy1) : fy1;
         auto emit = [&](bool keep, int px, int row, int sc) {
             // (x of the lane's px 0, frame, owner) of the lane that holds the pixel
             const uint32_t li = __builtin_amdgcn_ds_bpermute((px >> 2) << 2, (int)linfo);
@@ -649,12 +677,12 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         PHASE(3);
         // ---- next group's rows out of their registers (mirrored bytes in place), loads of the group after that ----
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
+        for (int u = 0; u < kG; u++) {
             cur[u] = __builtin_amdgcn_perm(0u, pre[u], R.sel);
             asm volatile("" : "+v"(cur[u]) : : "memory");      // here, not sunk to the loop end behind this group's stores
         }
 #pragma unroll
-        for (int u = 0; u < 7; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t0 + 14 + u), in_off);
+        for (int u = 0; u < kG; u++) pre[u] = gload_sv<u32_unaligned>(row_ptr(t0 + 2 * kG + u), in_off);
         PHASE(5);
         // the batch whose slice this group's NMS phase reserved: the waits of the rows above have outlasted its atomic (vmcnt
         // counts in order), so the result is read here for free. It must not stay in its register across the loop's back
@@ -667,7 +695,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         //      blends its 4 pixels from the ring (v_perm + v_dot2_u32_u16, the integers of k_resize_lds); the horizontal
         //      blend of the lower source row is kept for the next output row, which starts there 5 times out of 6. ----
         if (pyr) {
-            const int ring_last = min(t0 + 6, min(t_last, h - 1));    // last level row in the ring
+            const int ring_last = min(t0 + kG - 1, min(t_last, h - 1));    // last level row in the ring
             constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
             while (dy_next < gn_h && dy_next < yt_base + 64) {
                 dy_next = __builtin_amdgcn_readfirstlane(dy_next);
