@@ -12,7 +12,11 @@
 #   <T>_pmc_traffic.json              HBM bytes per frame and kernel from PMC FETCH_SIZE / WRITE_SIZE (separate passes)
 #   <T>_sq_counters.txt               SQ counter passes of the extractor kernels (tools/pmc_sq_r3.sh, 4096 frames)
 # Usage: tools/refresh_profiles.sh <tag>
-T=${1:-r3_x}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+T=${1:-r4_x}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+# PMC traffic FIRST, installed as profiles/pmc_traffic_r4.json (with the sha256 of the kernel source it was measured on), so that
+# the bench line below carries this build's traffic and traffic_stale: false
+cd $R && PAIRS=2048 ITERS=1 bash tools/pmc_traffic.sh 4096 > $O/${T}_pmc.log 2>&1 || { echo pmc failed; tail -5 $O/${T}_pmc.log; exit 1; }
+cp $O/pmc_traffic_4096.json $O/${T}_pmc_traffic.json; cp $O/pmc_traffic_4096.json $R/profiles/pmc_traffic_r4.json
 cd $R && timeout -k 10 500 python3 bench.py > $O/${T}_bench.log 2> $O/${T}_bench.err || { echo bench failed; tail -5 $O/${T}_bench.err; exit 1; }
 tail -1 $O/${T}_bench.log > $O/${T}_bench.json
 cd /tmp; export TMPDIR=/tmp
@@ -25,8 +29,11 @@ python3 $R/tools/level_times.py $db 640 480 8192 > $O/${T}_levels_640x480.txt
 rm -rf $O/${T}_stats1408
 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/${T}_stats1408 -o run -- python3 $R/tools/prof_extract.py --pairs 512 --iters 3 --chunk 1024 --width 1408 --height 1408 --features 4000 > $O/${T}_stats1408.log 2>&1 || { echo rocprof 1408 failed; tail -5 $O/${T}_stats1408.log; exit 1; }
 python3 $R/tools/level_times.py $(find $O/${T}_stats1408 -name "*.db" | head -1) 1408 1408 1024 > $O/${T}_levels_1408x1408.txt
-cd $R && PAIRS=2048 ITERS=1 bash tools/pmc_traffic.sh 4096 > $O/${T}_pmc.log 2>&1 || { echo pmc failed; tail -5 $O/${T}_pmc.log; exit 1; }
-cp $O/pmc_traffic_4096.json $O/${T}_pmc_traffic.json
 cd $R && bash tools/pmc_sq_r3.sh ${T} > /dev/null 2>&1; cp $O/pmc_sq_${T}.txt $O/${T}_sq_counters.txt
 rm -rf $O/${T}_stats $O/${T}_stats1408
+# the other configurations (BASELINE configs[3] at its per-GPU size, the EuRoC size, the north star's second size at 2000 kp)
+cd $R && timeout -k 10 400 python3 bench.py --width 1408 --height 1408 --features 4000 --pairs 2048 --no-cpu-baseline 2> /dev/null | tail -1 > $O/${T}_bench_1408x1408_4000kp_4096frames.json
+cd $R && timeout -k 10 300 python3 bench.py --width 752 --height 480 --features 1000 --no-cpu-baseline 2> /dev/null | tail -1 > $O/${T}_bench_752x480_1000kp.json
+cd $R && timeout -k 10 300 python3 bench.py --width 1408 --height 1408 --features 2000 --pairs 1024 --no-cpu-baseline 2> /dev/null | tail -1 > $O/${T}_bench_1408x1408_2000kp.json
+cd $R && bash tools/pmc_sq_matcher.sh ${T} > /dev/null 2>&1; cp $O/pmc_sq_matcher_${T}.txt $O/${T}_sq_counters_matcher.txt
 echo refreshed $T
