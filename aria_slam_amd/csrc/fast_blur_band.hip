@@ -121,25 +121,9 @@ __device__ __forceinline__ int fast_score_pk(const uint8_t* c, int pitch) {
     const uint8_t* rm3 = c - 3 * pitch; const uint8_t* rm2 = c - 2 * pitch; const uint8_t* rm1 = c - pitch;
     const uint8_t* rp1 = c + pitch; const uint8_t* rp2 = c + 2 * pitch; const uint8_t* rp3 = c + 3 * pitch;
     const uint32_t v = c[0];
-    const uint32_t vhi = v << 16;
     uint32_t ring[16] = {rp3[0], rp3[1], rp2[2], rp1[3], c[3], rm1[3], rm2[2], rm3[1],
                          rm3[0], rm3[-1], rm2[-2], rm1[-3], c[-3], rp1[-3], rp2[-2], rp3[-1]};
-    uint32_t P[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) P[k] = pk_sub_i16(v | (ring[k] << 16), ring[k] | vhi);
-    uint32_t M2[16], M4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) M2[k] = pk_min_i16(P[k], P[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) M4[k] = pk_min_i16(M2[k], M2[(k + 2) & 15]);
-    uint32_t Q = 0x80008000u;   // (-32768, -32768)
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t m9 = pk_min_i16(pk_min_i16(M4[k], M4[(k + 4) & 15]), P[(k + 8) & 15]);
-        Q = pk_max_i16(Q, m9);
-    }
-    const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
-    return max(q0, q1) - 1;
+    return fast9_score_f16(v, ring);      // packed half floats, three-input minimum / maximum (orb_device.h, round 4)
 }
 
 template <int TIE_EVEN, int NB1>

@@ -135,14 +135,7 @@ static_assert(kG == 7 || kG == 8, "the window holds 7 rows; 8 makes groups whole
 // min(v - ring) and of min(ring - v), minus 1; both polarities ride in one register as a packed pair. The pixel is a
 // FAST-9 corner for threshold t iff the result is >= t. (k_fast_blur_band's fast_score_pk on ring addresses.)
 //
-// Round 4: the pair is packed HALF FLOATS, not int16. A byte b in the low bits of a half (0x00bb) is the subnormal
-// b * 2^-24 -- the subnormals and the first normal binade of binary16 are one linear ramp up to 0x07ff -- so v_pk_add_f16
-// of (v | ring << 16) and its half-swapped, negated self is exactly (v - ring, ring - v) * 2^-24 (|d| <= 255: exact, the
-// kernel runs with half denormals enabled like every HIP kernel), and gfx950 has THREE-input packed minimum / maximum for
-// halves (v_pk_minimum3_f16 / v_pk_maximum3_f16, same issue class as v_pk_min_i16: profiles/r2_valu_issue_rates.txt):
-// the nine-arc minima are min3 of min3 (32 instructions instead of 64 two-input ones) and the maximum over the 16 arcs is
-// 8 instead of 16. A non-negative result's bit pattern IS the integer; negative ones (sign-magnitude) read as negative
-// int16, and a negative score is never a corner.
+// Round 4: the pair is packed HALF floats and the trees use three-input minimum / maximum: fast9_score_f16 (orb_device.h).
 __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int row) {
     const uint8_t* rm3 = ring + ring_off(row - 3) + px; const uint8_t* rm2 = ring + ring_off(row - 2) + px;
     const uint8_t* rm1 = ring + ring_off(row - 1) + px; const uint8_t* c = ring + ring_off(row) + px;
@@ -151,30 +144,10 @@ __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int 
     const uint32_t v = c[0];
     uint32_t rg[16] = {rp3[0], rp3[1], rp2[2], rp1[3], c[3], rm1[3], rm2[2], rm3[1],
                        rm3[0], rm3[-1], rm2[-2], rm1[-3], c[-3], rp1[-3], rp2[-2], rp3[-1]};
-    uint32_t Pk[16];
 #if ARIA_SCORE_F16
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t x = v | (rg[k] << 16);
-        asm("v_pk_add_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Pk[k]) : "v"(x));
-    }
-    uint32_t M3[16], M9[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(M3[k]) : "v"(Pk[k]), "v"(Pk[(k + 1) & 15]), "v"(Pk[(k + 2) & 15]));
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(M9[k]) : "v"(M3[k]), "v"(M3[(k + 3) & 15]), "v"(M3[(k + 6) & 15]));
-    uint32_t A5[6];
-#pragma unroll
-    for (int k = 0; k < 5; k++)
-        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(A5[k]) : "v"(M9[3 * k]), "v"(M9[3 * k + 1]), "v"(M9[3 * k + 2]));
-    A5[5] = M9[15];
-    uint32_t B0, B1, Q;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(B0) : "v"(A5[0]), "v"(A5[1]), "v"(A5[2]));
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(B1) : "v"(A5[3]), "v"(A5[4]), "v"(A5[5]));
-    asm("v_pk_max_f16 %0, %1, %2" : "=v"(Q) : "v"(B0), "v"(B1));
+    return fast9_score_f16(v, rg);
 #else
+    uint32_t Pk[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         // (v - ring, ring - v) from ONE packed register (v | ring << 16) and itself with the halves swapped (op_sel of the
@@ -194,9 +167,9 @@ __device__ __forceinline__ int fast_score_ring(const uint8_t* ring, int px, int 
         const uint32_t m9 = pk_min_i16(pk_min_i16(M4[k], M4[(k + 4) & 15]), Pk[(k + 8) & 15]);
         Q = pk_max_i16(Q, m9);
     }
-#endif
     const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
     return max(q0, q1) - 1;
+#endif
 }
 
 // What a lane is, fixed for the life of the wave.

@@ -35,4 +35,41 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
+// fast_score.cpp cornerScore<16> from the centre pixel v and its 16 ring pixels (in ring order): max over the 16 nine-arcs of
+// min(v - ring) and of min(ring - v), minus 1; the pixel is a FAST-9 corner for threshold t iff the result is >= t.
+// Both polarities ride in one register as a packed pair of HALF FLOATS (round 4): a byte b in the low bits of a half (0x00bb)
+// is the subnormal b * 2^-24 -- the subnormals and the first normal binade of binary16 are one linear ramp up to 0x07ff --
+// so v_pk_add_f16 of (v | ring << 16) and its half-swapped, negated self is exactly (v - ring, ring - v) * 2^-24 (|d| <= 255:
+// exact; HIP kernels run with half denormals enabled), and gfx950 has THREE-input packed minimum / maximum for halves
+// (v_pk_minimum3_f16 / v_pk_maximum3_f16, the issue class of v_pk_min_i16: profiles/r2_valu_issue_rates.txt): the nine-arc
+// minima are min3 of min3 (32 instructions instead of 64 two-input ones) and the maximum over the 16 arcs takes 7 instead
+// of 16. A non-negative result's bit pattern IS the integer; negative ones (sign-magnitude) read as negative int16, and a
+// negative score is never a corner. Used by k_fast_blur_stream (batches) and k_fast_blur_band (single frames).
+__device__ __forceinline__ int fast9_score_f16(uint32_t v, const uint32_t (&rg)[16]) {
+    uint32_t Pk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = v | (rg[k] << 16);
+        asm("v_pk_add_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Pk[k]) : "v"(x));
+    }
+    uint32_t M3[16], M9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(M3[k]) : "v"(Pk[k]), "v"(Pk[(k + 1) & 15]), "v"(Pk[(k + 2) & 15]));
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(M9[k]) : "v"(M3[k]), "v"(M3[(k + 3) & 15]), "v"(M3[(k + 6) & 15]));
+    uint32_t A5[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(A5[k]) : "v"(M9[3 * k]), "v"(M9[3 * k + 1]), "v"(M9[3 * k + 2]));
+    A5[5] = M9[15];
+    uint32_t B0, B1, Q;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(B0) : "v"(A5[0]), "v"(A5[1]), "v"(A5[2]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(B1) : "v"(A5[3]), "v"(A5[4]), "v"(A5[5]));
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(Q) : "v"(B0), "v"(B1));
+    const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
+    return max(q0, q1) - 1;
+}
+
 }  // namespace aria

@@ -60,7 +60,7 @@ struct FrameRecord {
     bool is_keyframe = false;
     long long loop_match_id = -1;
     double loop_score = 0.0;
-    std::unique_ptr<core::Frame> frame;      // kept only for the loop-closure step of a sharded run
+    std::unique_ptr<core::Frame> frame;      // kept only for the loop-closure step of a sharded / batched run, and only if it can be a keyframe
 };
 
 std::uint64_t frame_hash(const core::Frame& f, const std::vector<core::Match>& m) {
@@ -139,7 +139,9 @@ int main(int argc, char** argv) {
                     o.keypoints = f.numKeypoints();
                     o.matches = m.size();
                     o.hash = frame_hash(f, m);
-                    if (posthoc_loop) o.frame = std::make_unique<core::Frame>(f);
+                    // only frames that can become keyframes are kept for the loop step (>= keyframe_min_matches matches,
+                    // euroc_eval.cpp:179): a long sequence does not hold a copy of every frame until the end
+                    if (posthoc_loop && (int)m.size() >= pipeline::FrontEndConfig{}.keyframe_min_matches) o.frame = std::make_unique<core::Frame>(f);
                     ++done;
                 });
                 bstats[(size_t)s] = bfe.stats();
@@ -165,7 +167,7 @@ int main(int argc, char** argv) {
                 o.hash = frame_hash(*r.frame, r.matches);
                 o.is_keyframe = r.is_keyframe;
                 if (r.loop) { o.loop_match_id = (long long)r.loop->match_id; o.loop_score = r.loop->score; }
-                if (posthoc_loop) o.frame = std::make_unique<core::Frame>(*r.frame);
+                if (posthoc_loop && (int)r.matches.size() >= fc.frontend.keyframe_min_matches) o.frame = std::make_unique<core::Frame>(*r.frame);
                 const std::size_t d = ++done;
                 if (s == 0) { w = fw; h = fh; }
                 if (!sharded && d % 100 == 0) {                            // euroc_eval.cpp:271-277
