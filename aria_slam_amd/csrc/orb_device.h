@@ -45,7 +45,51 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // minima are min3 of min3 (32 instructions instead of 64 two-input ones) and the maximum over the 16 arcs takes 7 instead
 // of 16. A non-negative result's bit pattern IS the integer; negative ones (sign-magnitude) read as negative int16, and a
 // negative score is never a corner. Used by k_fast_blur_stream (batches) and k_fast_blur_band (single frames).
+#ifndef ARIA_SCORE_PAIRED
+#define ARIA_SCORE_PAIRED 1
+#endif
 __device__ __forceinline__ int fast9_score_f16(uint32_t v, const uint32_t (&rg)[16]) {
+#if ARIA_SCORE_PAIRED
+    // One polarity, TWO ring points per register: R_j = (v - ring_j, v - ring_{j+8}), j = 0..7 -- one v_lshl_or and one
+    // v_pk_add_f16 per PAIR of ring points (17 instructions to build instead of 32). Ring point j + 8 is the other half of
+    // register j, so "R_{j+8}" is R_j with its halves swapped, which the packed instructions take as an operand modifier
+    // (op_sel): the nine-arc minima A_k = min(D_k .. D_{k+8}) come out as M9_j = (A_j, A_{j+8}) from 8 + 8 three-input
+    // minima, the nine-arc maxima likewise. darker score = max_k A_k, brighter score = -min_k (max arc): 8 more.
+    const uint32_t vv = v | (v << 16);
+    uint32_t R[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t x = rg[j] | (rg[j + 8] << 16);
+        asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(R[j]) : "v"(vv), "v"(x));
+    }
+    // three-input min / max of registers i0, i1, i2 of an 8-register ring whose indices >= 8 mean "halves swapped"
+#define ARIA_PK3(OP, dst, src, i0, i1, i2)                                                                                       \
+    do {                                                                                                                         \
+        if ((i2) < 8) asm(OP " %0, %1, %2, %3" : "=v"(dst) : "v"(src[(i0) & 7]), "v"(src[(i1) & 7]), "v"(src[(i2) & 7]));          \
+        else if ((i1) < 8) asm(OP " %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(dst) : "v"(src[(i0) & 7]), "v"(src[(i1) & 7]), "v"(src[(i2) & 7])); \
+        else asm(OP " %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(dst) : "v"(src[(i0) & 7]), "v"(src[(i1) & 7]), "v"(src[(i2) & 7])); \
+    } while (0)
+    uint32_t m3[8], m9[8], x3[8], x9[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ARIA_PK3("v_pk_minimum3_f16", m3[j], R, j, j + 1, j + 2); ARIA_PK3("v_pk_maximum3_f16", x3[j], R, j, j + 1, j + 2); }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ARIA_PK3("v_pk_minimum3_f16", m9[j], m3, j, j + 3, j + 6); ARIA_PK3("v_pk_maximum3_f16", x9[j], x3, j, j + 3, j + 6); }
+#undef ARIA_PK3
+    uint32_t da, db, dk, ba, bb, br;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(da) : "v"(m9[0]), "v"(m9[1]), "v"(m9[2]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(db) : "v"(m9[3]), "v"(m9[4]), "v"(m9[5]));
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(da) : "v"(da), "v"(m9[6]), "v"(m9[7]));
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(dk) : "v"(da), "v"(db));                       // (max A_j over even half, over odd half)
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(ba) : "v"(x9[0]), "v"(x9[1]), "v"(x9[2]));
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(bb) : "v"(x9[3]), "v"(x9[4]), "v"(x9[5]));
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(ba) : "v"(ba), "v"(x9[6]), "v"(x9[7]));
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(br) : "v"(ba), "v"(bb));
+    // Q = max(dk, -br) per half: the sign flip of a half float is its top bit
+    uint32_t Q;
+    asm("v_pk_max_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Q) : "v"(dk), "v"(br));
+    const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
+    return max(q0, q1) - 1;
+#else
     uint32_t Pk[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -70,6 +114,7 @@ __device__ __forceinline__ int fast9_score_f16(uint32_t v, const uint32_t (&rg)[
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(Q) : "v"(B0), "v"(B1));
     const int q0 = (int)(short)(Q & 0xFFFFu), q1 = (int)(short)(Q >> 16);
     return max(q0, q1) - 1;
+#endif
 }
 
 }  // namespace aria
