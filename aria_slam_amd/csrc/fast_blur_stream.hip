@@ -55,28 +55,7 @@ typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Global accesses as "wave-uniform 64-bit base in SGPRs + the lane's 32-bit offset" (global_load/store v_off, s[base]).
-// Left alone the compiler folds the lane's constant offset into a 64-bit VGPR base and pays a v_mad_i64_i32 (and a VGPR
-// pair) per row load and store; the empty asm pins the row base to the scalar unit (243 -> 69 of them in the object; the
-// Q4 build 1.739 -> 1.703 us per frame), the address space keeps the access global (an integer turned pointer would be a
-// FLAT access, which also counts on lgkmcnt). (Round 4: also pinning the lane offset with an empty "+v" asm keeps its
-// zero-extension in the block, and every row load / store then takes the saddr form -- global_store_dword v_off, v, s[b:b+1]
-// -- instead of a v_lshl_add_u64 per access: 147 VGPRs, no faster: 0.2015 / 0.1992 against 0.2025 / 0.2009 A B A B.)
-template <typename T>
-__device__ __forceinline__ T gload_sv(const uint8_t* base, uint32_t off) {
-    uint64_t b = reinterpret_cast<uint64_t>(base);
-    asm volatile("" : "+s"(b));
-    typedef const T __attribute__((address_space(1))) * gp;
-    return *reinterpret_cast<gp>(b + off);
-}
-template <typename T>
-__device__ __forceinline__ void gstore_sv(uint8_t* base, uint32_t off, T v) {
-    uint64_t b = reinterpret_cast<uint64_t>(base);
-    asm volatile("" : "+s"(b));
-    typedef T __attribute__((address_space(1))) * gp;
-    *reinterpret_cast<gp>(b + off) = v;
-}
-
+// (gload_sv / gstore_sv: wave-uniform 64-bit base in SGPRs + the lane's 32-bit offset -- orb_device.h)
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
 }

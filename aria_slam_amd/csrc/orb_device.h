@@ -28,6 +28,28 @@ __device__ __host__ __forceinline__ int64_t q4_offset(int x, int y, int pitch) {
     return (int64_t)(y >> 2) * 4 * pitch + (int64_t)(x >> 2) * 16 + (y & 3) * 4 + (x & 3);
 }
 
+// Global accesses as "wave-uniform 64-bit base in SGPRs + the lane's 32-bit offset" (global_load/store v_off, s[base]).
+// Left alone the compiler folds the lane's constant offset into a 64-bit VGPR base and pays a v_mad_i64_i32 (and a VGPR
+// pair) per row load and store; the empty asm pins the row base to the scalar unit (243 -> 69 of them in the object; the
+// Q4 build 1.739 -> 1.703 us per frame), the address space keeps the access global (an integer turned pointer would be a
+// FLAT access, which also counts on lgkmcnt). (Round 4: also pinning the lane offset with an empty "+v" asm keeps its
+// zero-extension in the block, and every row load / store then takes the saddr form -- global_store_dword v_off, v, s[b:b+1]
+// -- instead of a v_lshl_add_u64 per access: 147 VGPRs, no faster: 0.2015 / 0.1992 against 0.2025 / 0.2009 A B A B.)
+template <typename T>
+__device__ __forceinline__ T gload_sv(const uint8_t* base, uint32_t off) {
+    uint64_t b = reinterpret_cast<uint64_t>(base);
+    asm volatile("" : "+s"(b));
+    typedef const T __attribute__((address_space(1))) * gp;
+    return *reinterpret_cast<gp>(b + off);
+}
+template <typename T>
+__device__ __forceinline__ void gstore_sv(uint8_t* base, uint32_t off, T v) {
+    uint64_t b = reinterpret_cast<uint64_t>(base);
+    asm volatile("" : "+s"(b));
+    typedef T __attribute__((address_space(1))) * gp;
+    *reinterpret_cast<gp>(b + off) = v;
+}
+
 __device__ __forceinline__ int reflect101(int i, int n) {
     // BORDER_REFLECT_101; inputs here never lie more than one period outside, clamp guards tiny levels
     if (i < 0) i = -i;
