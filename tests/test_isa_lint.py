@@ -60,3 +60,15 @@ def test_lint_recognises_the_hazard_form():
             "v_pk_sub_i16 v1, v2, v2 op_sel:[0,1] op_sel_hi:[1,0]"]                          # 16-bit packed: not the hazard's class
     crossed, broadcast = S.swizzled_pk_f32(body)
     assert crossed == body[:2] and broadcast == body[2:4]
+
+
+@pytest.mark.parametrize("src_name", ["fast_blur_stream.hip", "fast_blur_band.hip"])
+def test_fast_score_kernels_keep_half_denormals(src_name):
+    """fast9_score_f16 (orb_device.h, round 4) computes the FAST arcs on bytes read as HALF-FLOAT SUBNORMALS (0x00bb =
+    b * 2^-24): every kernel that contains it must run with half denormals enabled (the HIP default,
+    .amdhsa_float_denorm_mode_16_64 3) -- a build flag that flushed them would turn every difference into 0 silently on the
+    CPU side of the build; the GPU parity tests would catch it, this catches it without a GPU."""
+    text = _listing(src_name)
+    assert "v_pk_minimum3_f16" in text and "v_pk_maximum3_f16" in text, "the half-float score is not in this build"
+    modes = [ln.split()[-1] for ln in text.splitlines() if ".amdhsa_float_denorm_mode_16_64" in ln]
+    assert modes and all(m == "3" for m in modes), modes
