@@ -309,3 +309,20 @@ def test_runtime_helpers_fail_loudly_without_a_device(aria):
     if os.path.exists(exe):
         out = subprocess.run([exe, "/nonexistent", "--batch", "8"], capture_output=True, text=True, timeout=60)
         assert out.returncode != 0 and "HIP device" in out.stderr
+
+
+@pytest.mark.gpu
+def test_euroc_frontend_batch_mode_reports_a_bad_sequence(aria, hostlib, tmp_path):
+    """Error behaviour of the chunked pipeline: an image of another size in the middle of the sequence (the batch entry point
+    takes one size per call) stops the run with a message naming the file and a non-zero exit code -- from the producer
+    thread, through the consumer, without hanging; the frame-at-a-time mode accepts such a sequence (the adapter re-creates
+    its handle, as OrbCudaExtractor would re-allocate its GpuMat)."""
+    seq, t0 = _make_dataset(aria, str(tmp_path), 6, w=320, h=240, shuffle=False)
+    cam = os.path.join(str(tmp_path), "mav0", "cam0", "data")
+    odd = "%d.png" % (t0 + 7 * 50_000_000)
+    open(os.path.join(cam, odd), "wb").write(write_png(np.zeros((200, 300), np.uint8) + 7))
+    exe = os.path.join(PKG, "euroc_frontend")
+    out = subprocess.run([exe, str(tmp_path), "500", "--batch", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and odd in out.stderr and "another size" in out.stderr, out.stdout + out.stderr
+    out = subprocess.run([exe, str(tmp_path), "500"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr

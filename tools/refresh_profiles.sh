@@ -29,6 +29,10 @@ python3 $R/tools/level_times.py $db 640 480 8192 > $O/${T}_levels_640x480.txt
 rm -rf $O/${T}_stats1408
 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/${T}_stats1408 -o run -- python3 $R/tools/prof_extract.py --pairs 512 --iters 3 --chunk 1024 --width 1408 --height 1408 --features 4000 > $O/${T}_stats1408.log 2>&1 || { echo rocprof 1408 failed; tail -5 $O/${T}_stats1408.log; exit 1; }
 python3 $R/tools/level_times.py $(find $O/${T}_stats1408 -name "*.db" | head -1) 1408 1408 1024 > $O/${T}_levels_1408x1408.txt
+# ... and at BASELINE configs[3]'s per-GPU batch (4096 frames per launch: every level has >= 6 rounds of waves)
+rm -rf $O/${T}_stats1408b
+timeout -k 10 400 rocprofv3 --kernel-trace -d $O/${T}_stats1408b -o run -- python3 $R/tools/prof_extract.py --pairs 2048 --iters 2 --chunk 4096 --width 1408 --height 1408 --features 4000 > $O/${T}_stats1408b.log 2>&1 && python3 $R/tools/level_times.py $(find $O/${T}_stats1408b -name "*.db" | head -1) 1408 1408 4096 > $O/${T}_levels_1408x1408_4096frames.txt
+rm -rf $O/${T}_stats1408b
 cd $R && bash tools/pmc_sq_r3.sh ${T} > /dev/null 2>&1; cp $O/pmc_sq_${T}.txt $O/${T}_sq_counters.txt
 rm -rf $O/${T}_stats $O/${T}_stats1408
 # the other configurations (BASELINE configs[3] at its per-GPU size, the EuRoC size, the north star's second size at 2000 kp)
