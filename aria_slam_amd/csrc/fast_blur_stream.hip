@@ -41,13 +41,26 @@ namespace aria {
 namespace {
 
 constexpr int kRing = 16;                         // rows of the raw ring and of the score ring (power of two)
+// ARIA_PROBE_4WAVES (timing probe only, WRONG results: no pyramid step, short lists -- tools/occupancy_probe_stream.sh): what a
+// fourth wave per SIMD would buy this kernel's instruction mix. Never defined in a product or variants build.
+#ifdef ARIA_PROBE_4WAVES
+constexpr int kQ1 = 128, kQ2 = 108;
+#else
 constexpr int kQ1 = 256;                          // survivor queue entries (appended in rounds of at most this many)
 constexpr int kQ2 = 512;                          // corner list entries (beyond: dense scan of the score ring)
+#endif
 constexpr int kHdrBytes = 64;                     // in front of the raw ring: lane 0's left-neighbour read lands here
 constexpr int kRawBytes = kRing * 256;
 constexpr int kMapBytes = kRing * 256;
+#ifdef ARIA_PROBE_4WAVES
+constexpr int kOut = 128, kMapPad = 16;           // (kOut >= 128: emit() flushes 64 at a time and appends up to 64 more)
+constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 10 240 B: 16 waves per CU
+#else
 constexpr int kOut = 128;                         // candidate out-list entries (record + frame), flushed 64 at a time
-constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + 64 + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 12.3 KB per wave
+constexpr int kMapPad = 64;                       // behind the score ring (its last row's right-neighbour read)
+constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 12.3 KB per wave
+#endif
+static_assert(kOut >= 128 && kQ1 >= 64 && kQ2 >= 64, "emit() appends up to 64 entries behind a 64-entry batch; the lists are filled 64 lanes at a time");
 constexpr int kOwned = 62;                        // productive lanes per wave (lanes 1..62)
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -211,7 +224,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     uint8_t* s_rawb = wl + kHdrBytes;
     uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
     uint32_t* s_mapw = reinterpret_cast<uint32_t*>(s_map);
-    uint32_t* s_q1 = reinterpret_cast<uint32_t*>(wl + kHdrBytes + kRawBytes + kMapBytes + 64);
+    uint32_t* s_q1 = reinterpret_cast<uint32_t*>(wl + kHdrBytes + kRawBytes + kMapBytes + kMapPad);
     uint32_t* s_q2 = s_q1 + kQ1;
     uint32_t* s_out = s_q2 + kQ2;              // [kOut] candidate records, [kOut] their frames
     uint32_t* s_outf = s_out + kOut;
@@ -247,7 +260,11 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     }
 
     // ---- the pyramid step: the lane hosts the output dword of level l+1 whose anchor source column lies in its 4 px ----
+#ifdef ARIA_PROBE_4WAVES
+    const bool pyr = false;
+#else
     const bool pyr = A.next != nullptr;
+#endif
     const int gn_w = A.next_w, gn_h = A.next_h;
     int host_gx = -1;
     uint32_t xw[4] = {0, 0, 0, 0}, xo[4] = {0, 0, 0, 0}, xs[4] = {0, 0, 0, 0};
@@ -832,7 +849,11 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
             A.xt = D.tab + gn.xtab; A.yt = D.tab + gn.ytab; A.xinv = D.tab + gn.xinv;
         }
         // (variants build: ARIA_STREAM_LDS_KB pads the workgroup's LDS to lower the occupancy -- how the kernel scales with waves per SIMD)
+#ifdef ARIA_PROBE_4WAVES
+        static const size_t lds_pad = [] { const char* e = std::getenv("ARIA_STREAM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+#else
         static const size_t lds_pad = [] { const char* e = aria_getenv("ARIA_STREAM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+#endif
 #define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), std::max((size_t)N * kWaveLds, lds_pad), st, A, d_stamps)
         if (d_stamps) hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), st);
         if (wpb == 1) ARIA_FS_LAUNCH(1); else if (wpb == 2) ARIA_FS_LAUNCH(2); else ARIA_FS_LAUNCH(4);
