@@ -49,7 +49,16 @@ constexpr int kQ1 = 128, kQ2 = 108;
 constexpr int kQ1 = 256;                          // survivor queue entries (appended in rounds of at most this many)
 constexpr int kQ2 = 512;                          // corner list entries (beyond: dense scan of the score ring)
 #endif
+// Compact lists (round 4): 16-bit survivor and corner entries, 4-byte candidate records, no pads -- 8192 + 2048 = 10 240 B per
+// wave with the SAME capacities (what a fourth wave per SIMD needs from the LDS side; today the registers still cap at 3).
+#ifndef ARIA_STREAM_COMPACT_LDS
+#define ARIA_STREAM_COMPACT_LDS 0
+#endif
+#if ARIA_STREAM_COMPACT_LDS
+constexpr int kHdrBytes = 0;                      // (no read of the rings goes below byte 0 of a row: scored pixels start at local px 3)
+#else
 constexpr int kHdrBytes = 64;                     // in front of the raw ring: lane 0's left-neighbour read lands here
+#endif
 constexpr int kRawBytes = kRing * 256;
 constexpr int kMapBytes = kRing * 256;
 #ifdef ARIA_PROBE_4WAVES
@@ -57,8 +66,15 @@ constexpr int kOut = 128, kMapPad = 16;           // (kOut >= 128: emit() flushe
 constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 10 240 B: 16 waves per CU
 #else
 constexpr int kOut = 128;                         // candidate out-list entries (record + frame), flushed 64 at a time
+#if ARIA_STREAM_COMPACT_LDS
+constexpr int kMapPad = 0;
+constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 2 * kQ1 + 2 * kQ2 + 4 * kOut;      // 10 240 B per wave
+typedef uint16_t qent_t;
+#else
 constexpr int kMapPad = 64;                       // behind the score ring (its last row's right-neighbour read)
 constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 12.3 KB per wave
+typedef uint32_t qent_t;
+#endif
 #endif
 static_assert(kOut >= 128 && kQ1 >= 64 && kQ2 >= 64, "emit() appends up to 64 entries behind a 64-entry batch; the lists are filled 64 lanes at a time");
 constexpr int kOwned = 62;                        // productive lanes per wave (lanes 1..62)
@@ -224,10 +240,12 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     uint8_t* s_rawb = wl + kHdrBytes;
     uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
     uint32_t* s_mapw = reinterpret_cast<uint32_t*>(s_map);
-    uint32_t* s_q1 = reinterpret_cast<uint32_t*>(wl + kHdrBytes + kRawBytes + kMapBytes + kMapPad);
-    uint32_t* s_q2 = s_q1 + kQ1;
-    uint32_t* s_out = s_q2 + kQ2;              // [kOut] candidate records, [kOut] their frames
+    qent_t* s_q1 = reinterpret_cast<qent_t*>(wl + kHdrBytes + kRawBytes + kMapBytes + kMapPad);
+    qent_t* s_q2 = s_q1 + kQ1;
+    uint32_t* s_out = reinterpret_cast<uint32_t*>(s_q2 + kQ2);      // [kOut] candidate records (+ [kOut] their frames in the wide form)
+#if !ARIA_STREAM_COMPACT_LDS
     uint32_t* s_outf = s_out + kOut;
+#endif
 
     // ---- addresses: wave-uniform 64-bit bases + 32-bit lane offsets ----
     const int pitch_in = A.src_pitch;
@@ -335,7 +353,11 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     // per-lane info for whoever processes a queue entry of this lane's pixels: x of px 0 | frame - frame0 | owner
     const uint32_t linfo = (uint32_t)(4 * max(R.gdw, 0)) | ((uint32_t)(R.frame - frame0) << 11) | (R.owner ? 1u << 31 : 0u);
 
+#if ARIA_STREAM_COMPACT_LDS
+    const uint32_t lane_hi = (uint32_t)lane << 5;      // queue entry of a survivor: lane << 5 | bit of accw (11 bits)
+#else
     const uint32_t lane_hi = (uint32_t)lane << 8;      // queue entry of a survivor: lane << 8 | bit of accw  (>> 6 = 4 * lane)
+#endif
     int q2n = 0;                 // corners waiting for their lower neighbours' scores (wave-uniform)
     bool dense = false;          // the corner list overflowed once: NMS scans the score ring from here on
     int nms_done = fy0 - 1;      // rows <= this have been through NMS (diagnostic-free: the dense path starts after it)
@@ -354,8 +376,18 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     auto take_batch = [&](uint32_t& rec, int& frame, bool& valid, uint32_t& leader, uint32_t& rank, int& my_count) {
         const int nb = min(outn, 64);
         valid = lane < nb;
+#if ARIA_STREAM_COMPACT_LDS
+        {   // compact record: local px | row << 8 | score << 19; x and the frame come from the lane that holds the pixel
+            const uint32_t rc = valid ? s_out[lane] : 0u;
+            const uint32_t lpx = rc & 0xFFu;
+            const uint32_t li = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lpx >> 2) << 2), (int)linfo);
+            rec = ((li & 0x7FFu) + (lpx & 3u)) | (((rc >> 8) & 0x7FFu) << 11) | ((rc >> 19) << 22);
+            frame = frame0 + (int)(valid ? ((li >> 11) & 0xFFFFFu) : 0u);
+        }
+#else
         rec = valid ? s_out[lane] : 0u;
         frame = frame0 + (int)(valid ? s_outf[lane] : 0u);
+#endif
         unsigned long long pend = __builtin_amdgcn_ballot_w64(valid);
         my_count = 0; leader = 0; rank = 0;
         while (pend) {
@@ -373,9 +405,15 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     };
     auto drop_batch = [&]() {            // entries 64.. move to the front
         const int nb = min(outn, 64);
+#if ARIA_STREAM_COMPACT_LDS
+        const uint32_t mr = lane + 64 < outn ? s_out[lane + 64] : 0u;
+        wave_sync();
+        if (lane + 64 < outn) s_out[lane] = mr;
+#else
         const uint32_t mr = lane + 64 < outn ? s_out[lane + 64] : 0u, mf = lane + 64 < outn ? s_outf[lane + 64] : 0u;
         wave_sync();
         if (lane + 64 < outn) { s_out[lane] = mr; s_outf[lane] = mf; }
+#endif
         outn -= nb;
         wave_sync();
     };
@@ -553,17 +591,22 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 while (accw && my < r0 + kQ1) {
                     const int b = 31 - __clz(accw);
                     accw &= ~(1u << b);
-                    s_q1[my - r0] = lane_hi | (uint32_t)b;
+                    s_q1[my - r0] = (qent_t)(lane_hi | (uint32_t)b);
                     my++;
                 }
                 wave_sync();
                 const int qn = min(kQ1, total - r0);
                 for (int i0 = 0; i0 < qn; i0 += 64) {
                     const int i = i0 + lane;
-                    const uint32_t eq = i < qn ? s_q1[i] : 0u;
+                    const uint32_t eq = i < qn ? (uint32_t)s_q1[i] : 0u;
                     // bit b of accw -> step u, pixel px (see accw above)
                     const int b = (int)(eq & 31u), hi16 = b >> 4, bb = 15 - (b & 15);
-                    const uint32_t e = ((eq >> 6) + (uint32_t)(((bb & 1) << 1) | hi16)) | ((uint32_t)(o_lo + (bb >> 1)) << 8);    // local px | row << 8
+#if ARIA_STREAM_COMPACT_LDS
+                    const uint32_t lane4 = (eq >> 3) & 0xFCu;          // 4 * lane
+#else
+                    const uint32_t lane4 = eq >> 6;
+#endif
+                    const uint32_t e = (lane4 + (uint32_t)(((bb & 1) << 1) | hi16)) | ((uint32_t)(o_lo + (bb >> 1)) << 8);    // local px | row << 8
                     int sc = 0;
                     if (i < qn) sc = fast_score_ring(s_rawb, (int)(e & 0xFFu), (int)(e >> 8));
                     const bool corner = i < qn && sc >= thr;
@@ -571,7 +614,12 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                     const unsigned long long cm = __builtin_amdgcn_ballot_w64(corner);
                     if (cm) {
                         const int at = q2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+#if ARIA_STREAM_COMPACT_LDS
+                        // corner entry: local px | ring slot << 8 (the score is in the score ring, the row follows from the slot)
+                        if (corner && at < kQ2) s_q2[at] = (qent_t)((e & 0xFFu) | ((((e >> 8) + 3u) & (kRing - 1)) << 8));
+#else
                         if (corner && at < kQ2) s_q2[at] = e | ((uint32_t)sc << 24);
+#endif
                         q2n += __popcll(cm);
                     }
                 }
@@ -596,8 +644,12 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 if (outn > kOut - 64) flush_sync(false);
                 const int at = outn + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
                 if (keep) {
+#if ARIA_STREAM_COMPACT_LDS
+                    s_out[at] = (uint32_t)px | ((uint32_t)row << 8) | ((uint32_t)sc << 19);
+#else
                     s_out[at] = (uint32_t)X | ((uint32_t)row << 11) | ((uint32_t)sc << 22);
                     s_outf[at] = (li >> 11) & 0xFFFFFu;
+#endif
                 }
                 outn += __popcll(km);
             }
@@ -606,8 +658,17 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
             int kept = 0;
             for (int i0 = 0; i0 < q2n; i0 += 64) {
                 const int i = i0 + lane;
+#if ARIA_STREAM_COMPACT_LDS
+                // live corner rows lie in [o_lo - 1, o_lo + 6]: the row follows from the ring slot relative to ref = o_lo - 8
+                const qent_t e = i < q2n ? s_q2[i] : (qent_t)0;
+                const int px = (int)(e & 0xFFu);
+                const int ref = o_lo - 8;
+                const int row = ref + ((((int)(e >> 8)) - (ref + 3)) & (kRing - 1));
+                const int sc = i < q2n ? (int)s_map[(((int)(e >> 8)) << 8) + px] : 0;
+#else
                 const uint32_t e = i < q2n ? s_q2[i] : 0u;
                 const int px = (int)(e & 0xFFu), row = (int)((e >> 8) & 0x7FFu), sc = (int)(e >> 24);
+#endif
                 const bool ready = i < q2n && row <= nms_hi;
                 const bool later = i < q2n && row > nms_hi;
                 bool keep = false;
@@ -724,8 +785,14 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #undef PHASE
 }
 
+// (ARIA_STREAM_FORCE4W: A/B builds only -- the register allocator is held to 128 VGPRs, i.e. 4 waves per SIMD, and spills the rest)
+#ifdef ARIA_STREAM_FORCE4W
+#define ARIA_STREAM_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define ARIA_STREAM_OCC
+#endif
 template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_fast_blur_stream(StreamArgs A, unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(64 * WPB) ARIA_STREAM_OCC void k_fast_blur_stream(StreamArgs A, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
