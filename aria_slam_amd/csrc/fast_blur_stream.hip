@@ -136,6 +136,9 @@ __device__ __forceinline__ int ring_off(int y) { return ((y + 3) & (kRing - 1)) 
 #ifndef ARIA_STREAM_G
 #define ARIA_STREAM_G 7
 #endif
+#ifndef ARIA_STREAM_SPLIT
+#define ARIA_STREAM_SPLIT 0
+#endif
 constexpr int kG = ARIA_STREAM_G;
 static_assert(kG == 7 || kG == 8, "the window holds 7 rows; 8 makes groups whole row quads");
 
@@ -217,7 +220,11 @@ struct StreamArgs {
 
 }  // namespace
 
-template <int WPB, bool TAIL>
+// FB: the wave does FAST + NMS + blur; PYR: it does the pyramid step. Both = the fused wave (round 3). ARIA_STREAM_SPLIT (round 4)
+// gives the two jobs to two waves of the same launch: the FAST/blur wave then fits 128 VGPRs and, with the compact lists,
+// 10 KB of LDS -- four waves per SIMD instead of three --, and the pyramid wave (a few dozen registers, memory-bound) runs
+// beside it on the same CUs.
+template <int WPB, bool TAIL, bool FB, bool PYR>
 __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __restrict__ wl, const int lane, const LaneRole R,
                                             const int frame0, const int seg, unsigned long long* __restrict__ stamps) {
     // diagnostic builds only (-DARIA_DIAG, ARIA_STREAM_STAMPS=1): s_memtime ticks per phase, summed over the waves of the
@@ -235,7 +242,9 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     const int r0 = seg * A.seg_rows, r1 = min(h, r0 + A.seg_rows);
     // (kG == 8: the first group's first OUTPUT row t_first - 3 is a multiple of 4 -- r0 is -- so that every group is two whole
     // row quads; the one or two extra rows above the segment cost a step each and feed no output)
-    const int t_first = kG == 8 ? r0 - 5 : (r0 == 0 ? -3 : r0 - 4), t_last = r1 == h ? h + 2 : r1 + 3;
+    // (a pyramid-only wave needs the rows its output rows blend: upper source rows r0 .. r1 - 1 and the row below the last one)
+    const int t_first = !FB ? r0 : (kG == 8 ? r0 - 5 : (r0 == 0 ? -3 : r0 - 4));
+    const int t_last = !FB ? min(r1, h - 1) : (r1 == h ? h + 2 : r1 + 3);
     uint32_t* s_raw = reinterpret_cast<uint32_t*>(wl + kHdrBytes);                 // [kRing][64] dwords
     uint8_t* s_rawb = wl + kHdrBytes;
     uint8_t* s_map = wl + kHdrBytes + kRawBytes;                                   // [kRing][256] scores
@@ -278,10 +287,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     }
 
     // ---- the pyramid step: the lane hosts the output dword of level l+1 whose anchor source column lies in its 4 px ----
-#ifdef ARIA_PROBE_4WAVES
+#if defined(ARIA_PROBE_4WAVES) || defined(ARIA_STREAM_NOPYR)
     const bool pyr = false;
 #else
-    const bool pyr = A.next != nullptr;
+    const bool pyr = PYR && A.next != nullptr;
 #endif
     const int gn_w = A.next_w, gn_h = A.next_h;
     int host_gx = -1;
@@ -367,8 +376,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     //      records are stored after the next rows have been taken out of their registers, a phase later. A wave never sits
     //      out an L2 atomic round trip (1-2 us each, once per group of rows, was a sixth of this kernel's time). ----
     int outn = 0;                        // entries in the out-list (wave-uniform)
-    uint32_t p_rec = 0, p_leader = 0, p_rank = 0;   // the batch whose slice has been requested: one entry per lane
-    int p_frame = 0, p_base = 0;
+    // the batch whose slice has been requested, one entry per lane: the record, and in one register the frame (relative to
+    // frame0, 20 bits), the leader lane of the frame's slice (6 bits) and the rank inside it (6 bits)
+    uint32_t p_rec = 0, p_meta = 0;
+    int p_base = 0;
     bool p_valid = false;
     bool pend_any = false;               // a batch is waiting for its slice (wave-uniform)
     // the first min(outn, 64) entries of the out-list, one per lane: record, frame, and per frame of the batch the leader
@@ -431,13 +442,16 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     auto flush_async = [&]() {
         wave_sync();
         int my_count;
-        take_batch(p_rec, p_frame, p_valid, p_leader, p_rank, my_count);
-        if (my_count > 0) p_base = atomicAdd(A.cand_cnt + p_frame * kLevels, my_count);
+        uint32_t leader, rank;
+        int frame;
+        take_batch(p_rec, frame, p_valid, leader, rank, my_count);
+        if (my_count > 0) p_base = atomicAdd(A.cand_cnt + frame * kLevels, my_count);
+        p_meta = (uint32_t)(frame - frame0) | (leader << 20) | (rank << 26);
         pend_any = true;
         drop_batch();
     };
     auto complete_pending = [&]() {
-        store_batch(p_rec, p_frame, p_valid, p_leader, p_rank, p_base);
+        store_batch(p_rec, frame0 + (int)(p_meta & 0xFFFFFu), p_valid, (p_meta >> 20) & 63u, p_meta >> 26, p_base);
         p_valid = false;
         pend_any = false;
     };
@@ -466,13 +480,14 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #pragma unroll
         for (int u = 0; u < kG; u++) {
             s_raw[(((t0 + u + 3) & (kRing - 1)) << 6) + lane] = cur[u];
-            s_mapw[(((t0 + u) & (kRing - 1)) << 6) + lane] = 0u;             // score row o = t - 3 (slot (o + 3) & 15)
+            if constexpr (FB) s_mapw[(((t0 + u) & (kRing - 1)) << 6) + lane] = 0u;             // score row o = t - 3 (slot (o + 3) & 15)
         }
         wave_sync();
         // y-table window of the pyramid step: refilled here, a whole walk ahead of its first use
         if (pyr && dy_next + kG + 2 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn_h - 1)]; }
         PHASE(0);
 
+        if constexpr (FB) {
         // ---- the walk: row pass, column pass + store, compass reject ----
         uint32_t accw = 0;     // survivors of this group: step u, px j -> bit (j&1 ? 31 : 15) - (j>>1) - 2u
         u32x4 qv = {0u, 0u, 0u, 0u};      // kG == 8: the four blurred dwords of the lane's row quad
@@ -705,6 +720,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         if (outn >= 64) flush_async();        // (the pending batch of the previous group was stored after its rows-in phase)
         wave_sync();
         PHASE(3);
+        }      // FB
         // ---- next group's rows out of their registers (mirrored bytes in place), loads of the group after that ----
 #pragma unroll
         for (int u = 0; u < kG; u++) {
@@ -719,7 +735,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         // edge: the compiler copies loop-carried values there, and the copy of a pending atomic result is an
         // s_waitcnt vmcnt(0) in EVERY group -- prefetched rows, pyramid stores, everything (3.2k of a group's 13.9k cycles by
         // the phase stamps).
-        if (pend_any) { complete_pending(); }
+        if constexpr (FB) { if (pend_any) { complete_pending(); } }
 
         // ---- a6.1 fused: rows of level l+1 whose two source rows are in the ring now. The lane that hosts an output dword
         //      blends its 4 pixels from the ring (v_perm + v_dot2_u32_u16, the integers of k_resize_lds); the horizontal
@@ -773,8 +789,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         }
         PHASE(4);
     }
-    if (pend_any) complete_pending();
-    flush_sync(true);
+    if constexpr (FB) {
+        if (pend_any) complete_pending();
+        flush_sync(true);
+    }
 #ifdef ARIA_DIAG
     if (stamps && lane == 0) {
 #pragma unroll
@@ -783,6 +801,143 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     }
 #endif
 #undef PHASE
+}
+
+// The pyramid step as a wave of its own (ARIA_STREAM_SPLIT): the panel / segment decomposition, lane roles, hosting rule and
+// arithmetic of stream_wave's pyramid phase, without anything else -- so that it can be shaped for what it is, a memory-latency-
+// bound stream: rows go through a 32-row LDS ring in groups of 16, with TWO groups of row loads in flight (32 registers; the
+// FAST/blur wave can afford 14), and a group's ~13 output rows are blended while the next rows arrive. Output rows are owned by
+// the segment that holds their upper source row, exactly as in the fused wave: every row of level l + 1 is written once.
+__device__ __forceinline__ void pyramid_wave(const StreamArgs& A, uint8_t* __restrict__ wl, const int lane, const LaneRole R,
+                                             const int frame0, const int seg) {
+    constexpr int GB = 16, RB = 32;
+    const int w = A.w, h = A.h;
+    const int r0 = seg * A.seg_rows, r1 = min(h, r0 + A.seg_rows);
+    const int t_first = r0, t_last = min(r1, h - 1);           // upper source rows r0 .. r1 - 1 and the row below the last one
+    uint32_t* s_raw = reinterpret_cast<uint32_t*>(wl);         // [RB][64] dwords (8 KB of the wave's allocation)
+    const uint8_t* s_rawb = wl;
+    auto roff = [](int y) { return (y & (RB - 1)) << 8; };
+
+    const int pitch_in = A.src_pitch;
+    const uint8_t* src0 = A.src + (int64_t)frame0 * A.src_fstride;
+    const int r4 = w & 3, D = (w + 3) >> 2;
+    int xload;
+    if (R.gdw < 0) xload = 1;
+    else if (R.gdw >= D) xload = r4 ? w - 9 + r4 : w - 5;
+    else if (r4 && R.gdw == D - 1) xload = w - 4;
+    else xload = 4 * R.gdw;
+    const uint32_t in_off = (uint32_t)((int64_t)(R.frame - frame0) * A.src_fstride + xload);
+
+    const int gn_w = A.next_w, gn_h = A.next_h;
+    int host_gx = -1;
+    uint32_t xw[4] = {0, 0, 0, 0}, xo[4] = {0, 0, 0, 0}, xs[4] = {0, 0, 0, 0};
+    uint32_t nout_off = 0;
+    const uint32_t* yt = A.yt;
+    uint8_t* next0 = A.next + (int64_t)frame0 * A.next_fstride;
+    if (R.owner) {
+        const uint32_t hv = A.xinv[R.gdw];
+        if (hv != 0xFFFFFFFFu) host_gx = (int)hv;
+    }
+    if (host_gx >= 0) {
+        const uint32_t* xt = A.xt;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t t = xt[min(4 * host_gx + i, gn_w - 1)];
+            const int ox = (int)(t & 0xFFFFu);
+            const uint32_t cx1 = t >> 16;
+            const int lpx = 4 * lane + (ox - 4 * R.gdw);
+            xw[i] = (256u - cx1) | (cx1 << 16);
+            xo[i] = (uint32_t)(lpx & ~3);
+            xs[i] = 0x0C010C00u + (uint32_t)(lpx & 3) * 0x00010001u;
+        }
+        nout_off = (uint32_t)((int64_t)(R.frame - frame0) * A.next_fstride + 4 * host_gx);
+    }
+    int dy_next = 0;
+    if (r0 > 0) {
+        dy_next = min(max((int)(((int64_t)(2 * r0 + 1) * gn_h) / (2 * h)) - 1, 0), gn_h - 1);
+        while (dy_next > 0 && (int)(yt[dy_next - 1] & 0xFFFFu) >= r0) dy_next--;
+        while (dy_next < gn_h && (int)(yt[dy_next] & 0xFFFFu) < r0) dy_next++;
+        dy_next = __builtin_amdgcn_readfirstlane(dy_next);
+    }
+    // The y-table word of an output row is wave-uniform: it comes through the SCALAR cache, one row ahead of its use (s_load:
+    // counted on lgkmcnt with the LDS reads the row waits for anyway). As a vector load it sat on vmcnt between the row reloads,
+    // and the compiler waited for it with vmcnt(0) -- i.e. for the reloads just issued, the whole memory latency per group.
+    typedef const uint32_t __attribute__((address_space(4))) * const_u32p;       // constant address space: a uniform index is an s_load
+    const const_u32p yts = reinterpret_cast<const_u32p>(reinterpret_cast<uint64_t>(yt));
+    uint32_t ty_n = yts[min(dy_next, gn_h - 1)];
+    uint32_t hprev[4] = {0u, 0u, 0u, 0u};
+    int hprev_row = -1;
+
+    auto row_ptr = [&](int t) -> const uint8_t* { return src0 + (int64_t)min(max(t, 0), t_last) * pitch_in; };
+    uint32_t b0[GB], b1[GB];
+#pragma unroll
+    for (int u = 0; u < GB; u++) b0[u] = gload_sv<u32_unaligned>(row_ptr(t_first + u), in_off);
+#pragma unroll
+    for (int u = 0; u < GB; u++) b1[u] = gload_sv<u32_unaligned>(row_ptr(t_first + GB + u), in_off);
+    const int G = (t_last - t_first + 1 + GB - 1) / GB;
+
+    // one group: its rows (mirrored bytes in place) into the ring, the loads of the group after next into the freed
+    // registers, then every output row whose two source rows are in the ring now
+    auto group = [&](uint32_t (&buf)[GB], int gi) {
+        const int t0 = t_first + GB * gi;
+#pragma unroll
+        for (int u = 0; u < GB; u++) s_raw[(((t0 + u) & (RB - 1)) << 6) + lane] = __builtin_amdgcn_perm(0u, buf[u], R.sel);
+#pragma unroll
+        for (int u = 0; u < GB; u++) buf[u] = gload_sv<u32_unaligned>(row_ptr(t0 + 2 * GB + u), in_off);
+        wave_sync();
+        const int ring_last = min(t0 + GB - 1, t_last);
+        constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};
+        while (dy_next < gn_h) {
+            dy_next = __builtin_amdgcn_readfirstlane(dy_next);
+            const uint32_t ty = ty_n;
+            const int oy = (int)(ty & 0xFFFFu);
+            const int rb = min(oy + 1, h - 1);
+            if (rb > ring_last || oy >= r1) break;
+            ty_n = yts[min(dy_next + 1, gn_h - 1)];
+            if (host_gx >= 0) {
+                const uint32_t cy1 = ty >> 16, cyp = (256u - cy1) | (cy1 << 16);
+                const uint8_t* rowa = s_rawb + roff(oy);
+                const uint8_t* rowb = s_rawb + roff(rb);
+                const bool reuse = oy == hprev_row;
+                uint32_t qb0[4], qb1[4], qa0[4] = {0, 0, 0, 0}, qa1[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t* qb = reinterpret_cast<const uint32_t*>(rowb + xo[i]);
+                    qb0[i] = qb[0]; qb1[i] = qb[1];
+                }
+                if (!reuse) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t* qa = reinterpret_cast<const uint32_t*>(rowa + xo[i]);
+                        qa0[i] = qa[0]; qa1[i] = qa[1];
+                    }
+                }
+                uint32_t outw = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const us2v wx = __builtin_bit_cast(us2v, xw[i]);
+                    uint32_t h0 = hprev[i];
+                    if (!reuse) h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, __builtin_amdgcn_perm(qa1[i], qa0[i], xs[i])), wx, 0u, false);
+                    const uint32_t bot = __builtin_amdgcn_perm(qb1[i], qb0[i], xs[i]);
+                    const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, bot), wx, 0u, false);
+                    const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, h0 | (h1 << 16)), __builtin_bit_cast(us2v, cyp), 32768u, false);
+                    outw = __builtin_amdgcn_perm(v, outw, put[i]);
+                    hprev[i] = h1;
+                }
+                gstore_sv<uint32_t>(next0 + (int64_t)dy_next * A.next_pitch, nout_off, outw);
+            }
+            hprev_row = rb;
+            dy_next++;
+        }
+        wave_sync();            // the next group's ring writes must not pass this group's ring reads
+    };
+    // (both calls unconditional: behind a condition the second buffer's reload is not a certain event for the compiler's
+    // wait-count bookkeeping, and the first buffer's rows are then taken out with vmcnt(0) -- the whole memory latency, every
+    // other group. A surplus group past the segment's end loads its last row again and finds no output row to produce.)
+    for (int gi = 0; gi < G; gi += 2) {
+        group(b0, gi);
+        group(b1, gi + 1);
+    }
 }
 
 // (ARIA_STREAM_FORCE4W: A/B builds only -- the register allocator is held to 128 VGPRs, i.e. 4 waves per SIMD, and spills the rest)
@@ -798,7 +953,18 @@ __global__ __launch_bounds__(64 * WPB) ARIA_STREAM_OCC void k_fast_blur_stream(S
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int w = A.w, h = A.h;
     const int D = (w + 3) >> 2, U = D + 2;
-    const int wave_id = (int)blockIdx.x * WPB + wv;
+    int wave_id = (int)blockIdx.x * WPB + wv;
+    // ARIA_STREAM_SPLIT: ids come in blocks of 16 -- eight FAST/blur waves (one per XCD: workgroups go round-robin to the XCDs by
+    // id), then the eight pyramid waves of the same panels -- so both jobs are spread evenly over the XCDs and the panel map
+    // below (XCD k gets a contiguous eighth of the panels) holds for each of them
+    bool role_pyr = false;
+    if (ARIA_STREAM_SPLIT && A.next != nullptr) {
+        // (which of a block's two rows of eight is the pyramid row follows the Thue-Morse sequence of the block index: with a
+        // plain alternation the XCD's k-th and (k+1)-th workgroup -- which its dispatcher deals to its CUs in turn -- were always
+        // one of each kind, every FAST/blur wave landed on the same half of the CUs and the launch took twice as long)
+        role_pyr = (((wave_id >> 3) ^ __popc(wave_id >> 4)) & 1) != 0;
+        wave_id = ((wave_id >> 4) << 3) | (wave_id & 7);
+    }
     // Workgroups go round-robin to the 8 XCDs (each with its own L2) by linear id. Neighbouring panels share the 128-byte
     // lines their 248-byte row pieces end in (rows are not cut at line boundaries), so XCD k is given a CONTIGUOUS eighth of
     // the panels: the shared lines are then fetched, and the partial lines written, by one L2 (before: 1.7x the level bytes
@@ -842,8 +1008,18 @@ __global__ __launch_bounds__(64 * WPB) ARIA_STREAM_OCC void k_fast_blur_stream(S
     }
     uint8_t* wl = smem + wv * kWaveLds;
     const bool any_tail = __builtin_amdgcn_ballot_w64(R.tailbits != 0) != 0;
-    if (any_tail) stream_wave<WPB, true>(A, wl, lane, R, frame0, seg, stamps);
-    else stream_wave<WPB, false>(A, wl, lane, R, frame0, seg, stamps);
+#if ARIA_STREAM_SPLIT
+#ifdef ARIA_PROBE_SPLIT_EMPTY_PYR
+    if (role_pyr) return;        // timing probe: what do the pyramid waves cost when they do nothing?
+#endif
+    if (role_pyr) pyramid_wave(A, wl, lane, R, frame0, seg);
+    else if (any_tail) stream_wave<WPB, true, true, false>(A, wl, lane, R, frame0, seg, stamps);
+    else stream_wave<WPB, false, true, false>(A, wl, lane, R, frame0, seg, stamps);
+#else
+    (void)role_pyr;
+    if (any_tail) stream_wave<WPB, true, true, true>(A, wl, lane, R, frame0, seg, stamps);
+    else stream_wave<WPB, false, true, true>(A, wl, lane, R, frame0, seg, stamps);
+#endif
 }
 
 // The batch path takes this kernel when every level is at least 16 px wide and high (tiny images stay with the band
@@ -900,7 +1076,8 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
         const int seg_rows = ((g.h + n_seg - 1) / n_seg + 3) & ~3;      // whole row quads: the lines of a quad of the blurred level are written by one wave
         n_seg = (g.h + seg_rows - 1) / seg_rows;
         const int64_t panels8 = (panels + 7) / 8;
-        const int64_t waves = 8 * panels8 * n_seg;
+        // (split build: as many pyramid waves again, interleaved in blocks of eight, for every level that has a next one)
+        const int64_t waves = 8 * panels8 * n_seg * ((ARIA_STREAM_SPLIT && l + 1 < kLevels) ? 2 : 1);
         const dim3 grid((unsigned)((waves + wpb - 1) / wpb));
         StreamArgs A{};
         A.seg_rows = seg_rows; A.n_seg = n_seg; A.panels = (int)panels; A.panels8 = (int)panels8;

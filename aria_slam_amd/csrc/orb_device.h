@@ -70,6 +70,9 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 #ifndef ARIA_SCORE_PAIRED
 #define ARIA_SCORE_PAIRED 1
 #endif
+#ifndef ARIA_SCORE_SEQ
+#define ARIA_SCORE_SEQ 0
+#endif
 __device__ __forceinline__ int fast9_score_f16(uint32_t v, const uint32_t (&rg)[16]) {
 #if ARIA_SCORE_PAIRED
     // One polarity, TWO ring points per register: R_j = (v - ring_j, v - ring_{j+8}), j = 0..7 -- one v_lshl_or and one
@@ -92,16 +95,33 @@ __device__ __forceinline__ int fast9_score_f16(uint32_t v, const uint32_t (&rg)[
         else asm(OP " %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(dst) : "v"(src[(i0) & 7]), "v"(src[(i1) & 7]), "v"(src[(i2) & 7])); \
     } while (0)
     uint32_t m3[8], m9[8], x3[8], x9[8];
+    uint32_t da, db, dk, ba, bb, br;
+#if ARIA_SCORE_SEQ
+    // the darker tree first, then the brighter one (the empty asm keeps the compiler from interleaving them: 8 registers of
+    // arcs in flight instead of 16 -- 5 VGPRs of the kernel's peak, which sits in this phase)
+#pragma unroll
+    for (int j = 0; j < 8; j++) ARIA_PK3("v_pk_minimum3_f16", m3[j], R, j, j + 1, j + 2);
+#pragma unroll
+    for (int j = 0; j < 8; j++) ARIA_PK3("v_pk_minimum3_f16", m9[j], m3, j, j + 3, j + 6);
+#else
 #pragma unroll
     for (int j = 0; j < 8; j++) { ARIA_PK3("v_pk_minimum3_f16", m3[j], R, j, j + 1, j + 2); ARIA_PK3("v_pk_maximum3_f16", x3[j], R, j, j + 1, j + 2); }
 #pragma unroll
     for (int j = 0; j < 8; j++) { ARIA_PK3("v_pk_minimum3_f16", m9[j], m3, j, j + 3, j + 6); ARIA_PK3("v_pk_maximum3_f16", x9[j], x3, j, j + 3, j + 6); }
-#undef ARIA_PK3
-    uint32_t da, db, dk, ba, bb, br;
+#endif
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(da) : "v"(m9[0]), "v"(m9[1]), "v"(m9[2]));
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(db) : "v"(m9[3]), "v"(m9[4]), "v"(m9[5]));
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(da) : "v"(da), "v"(m9[6]), "v"(m9[7]));
     asm("v_pk_max_f16 %0, %1, %2" : "=v"(dk) : "v"(da), "v"(db));                       // (max A_j over even half, over odd half)
+#if ARIA_SCORE_SEQ
+#pragma unroll
+    for (int j = 0; j < 8; j++) asm volatile("" : "+v"(R[j]) : "v"(dk));
+#pragma unroll
+    for (int j = 0; j < 8; j++) ARIA_PK3("v_pk_maximum3_f16", x3[j], R, j, j + 1, j + 2);
+#pragma unroll
+    for (int j = 0; j < 8; j++) ARIA_PK3("v_pk_maximum3_f16", x9[j], x3, j, j + 3, j + 6);
+#endif
+#undef ARIA_PK3
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(ba) : "v"(x9[0]), "v"(x9[1]), "v"(x9[2]));
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(bb) : "v"(x9[3]), "v"(x9[4]), "v"(x9[5]));
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(ba) : "v"(ba), "v"(x9[6]), "v"(x9[7]));
