@@ -41,18 +41,17 @@ namespace aria {
 namespace {
 
 constexpr int kRing = 16;                         // rows of the raw ring and of the score ring (power of two)
-// ARIA_PROBE_4WAVES (timing probe only, WRONG results: no pyramid step, short lists -- tools/occupancy_probe_stream.sh): what a
-// fourth wave per SIMD would buy this kernel's instruction mix. Never defined in a product or variants build.
-#ifdef ARIA_PROBE_4WAVES
-constexpr int kQ1 = 128, kQ2 = 108;
-#else
-constexpr int kQ1 = 256;                          // survivor queue entries (appended in rounds of at most this many)
-constexpr int kQ2 = 512;                          // corner list entries (beyond: dense scan of the score ring)
+// ARIA_STREAM_PEND_LDS (compact lists only): the record of the pending candidate batch waits for its slice in LDS instead
+// of a register (64 dwords taken from the corner list: 384 entries instead of 512, beyond which the dense scan takes over).
+#ifndef ARIA_STREAM_PEND_LDS
+#define ARIA_STREAM_PEND_LDS 1
 #endif
+constexpr int kQ1 = 256;                          // survivor queue entries (appended in rounds of at most this many)
+constexpr int kQ2 = ARIA_STREAM_PEND_LDS ? 384 : 512;      // corner list entries (beyond: dense scan of the score ring)
 // Compact lists (round 4): 16-bit survivor and corner entries, 4-byte candidate records, no pads -- 8192 + 2048 = 10 240 B per
-// wave with the SAME capacities (what a fourth wave per SIMD needs from the LDS side; today the registers still cap at 3).
+// wave: what a fourth wave per SIMD needs from the LDS side (ARIA_STREAM_WAVES4 below is the register side).
 #ifndef ARIA_STREAM_COMPACT_LDS
-#define ARIA_STREAM_COMPACT_LDS 0
+#define ARIA_STREAM_COMPACT_LDS 1
 #endif
 #if ARIA_STREAM_COMPACT_LDS
 constexpr int kHdrBytes = 0;                      // (no read of the rings goes below byte 0 of a row: scored pixels start at local px 3)
@@ -61,20 +60,16 @@ constexpr int kHdrBytes = 64;                     // in front of the raw ring: l
 #endif
 constexpr int kRawBytes = kRing * 256;
 constexpr int kMapBytes = kRing * 256;
-#ifdef ARIA_PROBE_4WAVES
-constexpr int kOut = 128, kMapPad = 16;           // (kOut >= 128: emit() flushes 64 at a time and appends up to 64 more)
-constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 10 240 B: 16 waves per CU
-#else
 constexpr int kOut = 128;                         // candidate out-list entries (record + frame), flushed 64 at a time
 #if ARIA_STREAM_COMPACT_LDS
 constexpr int kMapPad = 0;
-constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 2 * kQ1 + 2 * kQ2 + 4 * kOut;      // 10 240 B per wave
+constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 2 * kQ1 + 2 * kQ2 + 4 * kOut + (ARIA_STREAM_PEND_LDS ? 256 : 0);      // 10 240 B per wave
+static_assert(kWaveLds == 10240, "16 waves per CU");
 typedef uint16_t qent_t;
 #else
 constexpr int kMapPad = 64;                       // behind the score ring (its last row's right-neighbour read)
 constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 4 * kQ1 + 4 * kQ2 + 8 * kOut;      // 12.3 KB per wave
 typedef uint32_t qent_t;
-#endif
 #endif
 static_assert(kOut >= 128 && kQ1 >= 64 && kQ2 >= 64, "emit() appends up to 64 entries behind a 64-entry batch; the lists are filled 64 lanes at a time");
 constexpr int kOwned = 62;                        // productive lanes per wave (lanes 1..62)
@@ -136,10 +131,16 @@ __device__ __forceinline__ int ring_off(int y) { return ((y + 3) & (kRing - 1)) 
 #ifndef ARIA_STREAM_G
 #define ARIA_STREAM_G 7
 #endif
+// Flat walk: the three per-row range tests of the walk (row ingested / row in the segment / row in the FAST range) select
+// a predicate instead of branching, so that a group's seven rows are one basic block.
+#ifndef ARIA_STREAM_FLAT
+#define ARIA_STREAM_FLAT 1
+#endif
 #ifndef ARIA_STREAM_SPLIT
 #define ARIA_STREAM_SPLIT 0
 #endif
 constexpr int kG = ARIA_STREAM_G;
+static_assert(!ARIA_STREAM_FLAT || ARIA_COMPASS2, "the flat walk masks rows through the one-comparison compass test");
 static_assert(kG == 7 || kG == 8, "the window holds 7 rows; 8 makes groups whole row quads");
 
 // fast_score.cpp cornerScore<16> for local pixel px of row `row` of the wave's raw ring: max over the 16 nine-arcs of
@@ -254,6 +255,9 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     uint32_t* s_out = reinterpret_cast<uint32_t*>(s_q2 + kQ2);      // [kOut] candidate records (+ [kOut] their frames in the wide form)
 #if !ARIA_STREAM_COMPACT_LDS
     uint32_t* s_outf = s_out + kOut;
+    static_assert(!ARIA_STREAM_PEND_LDS, "ARIA_STREAM_PEND_LDS goes with the compact lists");
+#elif ARIA_STREAM_PEND_LDS
+    uint32_t* s_pend = s_out + kOut;           // [64] records of the batch whose slice has been requested
 #endif
 
     // ---- addresses: wave-uniform 64-bit bases + 32-bit lane offsets ----
@@ -287,7 +291,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     }
 
     // ---- the pyramid step: the lane hosts the output dword of level l+1 whose anchor source column lies in its 4 px ----
-#if defined(ARIA_PROBE_4WAVES) || defined(ARIA_STREAM_NOPYR)
+#if defined(ARIA_STREAM_NOPYR)
     const bool pyr = false;
 #else
     const bool pyr = PYR && A.next != nullptr;
@@ -331,7 +335,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     // the y-table words of 64 output rows at a time, one per lane (a load per row would put an L2 round trip in front of
     // every output row)
     int yt_base = dy_next;
-    uint32_t ytv = pyr ? yt[min(yt_base + lane, gn_h - 1)] : 0u;
+    uint32_t ytv = pyr ? gload_sv<uint32_t>(reinterpret_cast<const uint8_t*>(A.yt), 4u * (uint32_t)min(yt_base + lane, gn_h - 1)) : 0u;
     uint32_t hprev[4] = {0u, 0u, 0u, 0u};
     int hprev_row = -1;
 
@@ -445,12 +449,18 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         uint32_t leader, rank;
         int frame;
         take_batch(p_rec, frame, p_valid, leader, rank, my_count);
+#if ARIA_STREAM_PEND_LDS
+        s_pend[lane] = p_rec;                // (a lane reads its own slot back: no ordering with other lanes involved)
+#endif
         if (my_count > 0) p_base = atomicAdd(A.cand_cnt + frame * kLevels, my_count);
         p_meta = (uint32_t)(frame - frame0) | (leader << 20) | (rank << 26);
         pend_any = true;
         drop_batch();
     };
     auto complete_pending = [&]() {
+#if ARIA_STREAM_PEND_LDS
+        p_rec = s_pend[lane];
+#endif
         store_batch(p_rec, frame0 + (int)(p_meta & 0xFFFFFu), p_valid, (p_meta >> 20) & 63u, p_meta >> 26, p_base);
         p_valid = false;
         pend_any = false;
@@ -484,7 +494,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         }
         wave_sync();
         // y-table window of the pyramid step: refilled here, a whole walk ahead of its first use
-        if (pyr && dy_next + kG + 2 > yt_base + 64) { yt_base = dy_next; ytv = yt[min(yt_base + lane, gn_h - 1)]; }
+        if (pyr && dy_next + kG + 2 > yt_base + 64) { yt_base = dy_next; ytv = gload_sv<uint32_t>(reinterpret_cast<const uint8_t*>(A.yt), 4u * (uint32_t)min(yt_base + lane, gn_h - 1)); }
         PHASE(0);
 
         if constexpr (FB) {
@@ -494,7 +504,9 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #pragma unroll
         for (int u = 0; u < kG; u++) {
             const int t = t0 + u;
-            if (t <= t_last) {
+            // (flat walk: rows past t_last -- only in a segment's last group -- are copies of the last row, walked like any other;
+            // their outputs fail the two range tests below)
+            if (ARIA_STREAM_FLAT || t <= t_last) {
                 // neighbours' dwords straight from their registers (DPP wave shifts): no LDS round trip in the walk. Lane 0's
                 // left and lane 63's right neighbour do not exist (they read 0): those two lanes only provide pixels.
                 const uint32_t w1 = cur[u];
@@ -517,7 +529,8 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 // row o+d of the window lives in slot (u - 3 + d) mod kG
                 const int sC = (u + kG - 3) % kG, sM1 = (u + kG - 4) % kG, sP1 = (u + kG - 2) % kG, sM2 = (u + kG - 5) % kG,
                           sP2 = (u + kG - 1) % kG, sM3 = (u + kG - 6) % kG, sP3 = u;
-                if (o >= r0 && o < r1) {
+                const bool blur_row = o >= r0 && o < r1;
+                if (ARIA_STREAM_FLAT || blur_row) {
                     // vertical pass + rounding by 2^16 (filter.simd.hpp SymmColumnFilter / SymmColumnVec_32s8u). All values are
                     // integers * 2^-16 below 2^9, so the fp32 column pass is exact (a partial sum can only be inexact above
                     // 256.0, which saturates either way); v_cvt_pk_u8_f32 rounds to nearest EVEN (the SIMD path), saturates
@@ -546,11 +559,15 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                     // turns into four v_cndmask per row: 1.777 us; parking them in LDS under that index and storing 16 bytes
                     // per quad: +8 %; non-temporal stores: +35 % (the L2 no longer merges the rows of a line).
                     if constexpr (kG == 8) qv[u & 3] = outw;
-                    else if (R.owner) gstore_sv<uint32_t>(blur0 + (int64_t)(o >> 2) * (4 * A.blur_pitch) + ((o & 3) << 2), out_off, outw);
+                    else if (R.owner && blur_row) gstore_sv<uint32_t>(blur0 + (int64_t)(o >> 2) * (4 * A.blur_pitch) + ((o & 3) << 2), out_off, outw);
                 } else if constexpr (kG == 8) {
                     qv[u & 3] = 0u;           // rows outside the segment (or below the image, in the level's padded last quad)
                 }
-                if (o >= fy0 && o <= fy1) {
+                const bool fast_row = o >= fy0 && o <= fy1;
+                // (flat walk: a row outside the FAST range gets a threshold no difference reaches -- a scalar select -- instead of
+                // a branch around the test)
+                const uint32_t T2r = ARIA_STREAM_FLAT ? (fast_row ? T2 : 0x40004000u) : T2;
+                if (ARIA_STREAM_FLAT || fast_row) {
                     // compass reject, two pixels per packed-int16 op (see k_fast_blur_band): survive iff one of N, S AND one
                     // of E, W are darker than c - t, or the same with brighter than c + t
                     uint32_t pass[2];
@@ -566,7 +583,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                         const uint32_t X = pk_max_i16(pk_min_i16(n2, s2), pk_min_i16(e2, w2p));
                         const uint32_t Y = pk_min_i16(pk_max_i16(n2, s2), pk_max_i16(e2, w2p));
                         const uint32_t m = pk_max_i16(pk_sub_i16(c2, X), pk_sub_i16(Y, c2));
-                        pass[pr] = pk_sub_i16(T2, m) & (pr ? R.xm1 : R.xm0);
+                        pass[pr] = pk_sub_i16(T2r, m) & (pr ? R.xm1 : R.xm0);
 #else
                         const uint32_t lo = pk_sub_i16(c2, T2), hi = pk_add_i16(c2, T2);
                         const uint32_t dk = pk_sub_i16(pk_max_i16(pk_min_i16(n2, s2), pk_min_i16(e2, w2p)), lo);
@@ -940,8 +957,18 @@ __device__ __forceinline__ void pyramid_wave(const StreamArgs& A, uint8_t* __res
     }
 }
 
-// (ARIA_STREAM_FORCE4W: A/B builds only -- the register allocator is held to 128 VGPRs, i.e. 4 waves per SIMD, and spills the rest)
-#ifdef ARIA_STREAM_FORCE4W
+// FOUR waves per SIMD (round 4). The kernel needs <= 128 VGPRs and <= 10 240 B of LDS per wave for that; the compact lists give
+// the LDS, and with the flat walk, the pending record in LDS and the y-table through a scalar base the allocator gets to 128
+// registers when it is told to (left alone it stops at 138: it has no reason to go below the 168 of three waves). What it
+// still spills are five values that live through the group loop without being used in it: stored once in front of the
+// loop, loaded once behind it (24 bytes of scratch per lane, no scratch access inside the loop -- tests/test_isa_lint.py holds
+// the kernel to that). Measured A B A B on one box (tools/ab_levels.sh, 640x480 at 8192 frames): 1.481 against 1.581 us per
+// frame, 0.2157 / 0.2147 against 0.1995 / 0.2012 of 8 TB/s. ARIA_STREAM_WAVES4=0 restores the unconstrained allocation.
+#ifndef ARIA_STREAM_WAVES4
+#define ARIA_STREAM_WAVES4 1
+#endif
+#if ARIA_STREAM_WAVES4
+static_assert(ARIA_STREAM_COMPACT_LDS, "four waves per SIMD need the 10 240-byte LDS layout");
 #define ARIA_STREAM_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
 #define ARIA_STREAM_OCC
@@ -1093,11 +1120,7 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
             A.xt = D.tab + gn.xtab; A.yt = D.tab + gn.ytab; A.xinv = D.tab + gn.xinv;
         }
         // (variants build: ARIA_STREAM_LDS_KB pads the workgroup's LDS to lower the occupancy -- how the kernel scales with waves per SIMD)
-#ifdef ARIA_PROBE_4WAVES
-        static const size_t lds_pad = [] { const char* e = std::getenv("ARIA_STREAM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
-#else
         static const size_t lds_pad = [] { const char* e = aria_getenv("ARIA_STREAM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
-#endif
 #define ARIA_FS_LAUNCH(N) ARIA_LAUNCH(prof, (k_fast_blur_stream<N>), grid, dim3(64 * N), std::max((size_t)N * kWaveLds, lds_pad), st, A, d_stamps)
         if (d_stamps) hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), st);
         if (wpb == 1) ARIA_FS_LAUNCH(1); else if (wpb == 2) ARIA_FS_LAUNCH(2); else ARIA_FS_LAUNCH(4);

@@ -48,7 +48,24 @@ def test_no_crossed_half_packed_fp32(src_name, kernels):
         assert len(body) > 200, "kernel %s not found in the listing" % k
         crossed, _broadcast = S.swizzled_pk_f32(body)
         assert not crossed, "%s: packed fp32 with a crossed register half (the form of the round-3 hazard):\n%s" % (k, "\n".join(crossed[:8]))
-        assert meta.get("ScratchSize", 0) == 0, "%s spills to scratch" % k
+        if "k_fast_blur_stream" in k:
+            # held to 128 VGPRs (four waves per SIMD); what the allocator spills must stay OUTSIDE the loops: a reload is a
+            # vector-memory load, and waiting for it waits for every prefetched row issued before it (vmcnt counts in order)
+            assert meta.get("TotalNumVgprs", 999) <= 128 and meta.get("Occupancy") == 4, meta
+            in_loop, outside = S.scratch_accesses(text, k)
+            assert not in_loop, "%s: scratch access inside a loop:\n%s" % (k, "\n".join(in_loop[:8]))
+            assert meta.get("ScratchSize", 0) <= 32 and len(outside) <= 8, (meta, outside)
+        else:
+            assert meta.get("ScratchSize", 0) == 0, "%s spills to scratch" % k
+
+
+def test_lint_recognises_a_spill_inside_a_loop():
+    text = "\n".join(["_Z1kv:", "; %bb.0:", "\tscratch_store_dword off, v5, off offset:16", ".LBB0_1:    ; =>This Loop Header: Depth=1",
+                      "\tscratch_load_dword v5, off, off offset:16", "; %bb.2:      ;   in Loop: Header=BB0_1 Depth=1",
+                      "\tscratch_load_dword v6, off, off", ".LBB0_3:", "\tscratch_load_dword v7, off, off", "\ts_endpgm",
+                      "\t.section .rodata"])
+    in_loop, outside = S.scratch_accesses(text, "_Z1kv")
+    assert len(in_loop) == 2 and len(outside) == 2
 
 
 def test_lint_recognises_the_hazard_form():

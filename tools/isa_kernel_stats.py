@@ -38,6 +38,30 @@ def kernel_body(text, name_sub):
     return body, meta
 
 
+def scratch_accesses(text, name_sub):
+    """(in_loop, outside) scratch_load / scratch_store lines of the kernel: LLVM's listing marks every basic block that belongs
+    to a loop ("in Loop: Header=...", "Loop Header", "Parent Loop") on its label or its "; %bb.N:" comment."""
+    lines = text.splitlines()
+    start = None
+    for i, ln in enumerate(lines):
+        head = ln.split(";")[0].strip()
+        if head.endswith(":") and name_sub in head and not ln.startswith("\t") and not ln.startswith(".L"):
+            start = i
+            break
+    if start is None:
+        raise SystemExit("kernel %r not found" % name_sub)
+    in_loop, outside, looping = [], [], False
+    for ln in lines[start + 1:]:
+        t = ln.strip()
+        if t.startswith(".section") or t.startswith(".amdhsa_kernel"):
+            break
+        if t.startswith(".LBB") or t.startswith("; %bb."):
+            looping = "Loop" in t
+        elif t.startswith("scratch_"):
+            (in_loop if looping else outside).append(t)
+    return in_loop, outside
+
+
 def stats(body):
     hist = collections.Counter(ln.split()[0] for ln in body)
     waits = collections.Counter(ln for ln in body if ln.startswith("s_waitcnt"))
