@@ -40,4 +40,8 @@ cd $R && timeout -k 10 400 python3 bench.py --width 1408 --height 1408 --feature
 cd $R && timeout -k 10 300 python3 bench.py --width 752 --height 480 --features 1000 --no-cpu-baseline 2> /dev/null | tail -1 > $O/${T}_bench_752x480_1000kp.json
 cd $R && timeout -k 10 300 python3 bench.py --width 1408 --height 1408 --features 2000 --pairs 1024 --no-cpu-baseline 2> /dev/null | tail -1 > $O/${T}_bench_1408x1408_2000kp.json
 cd $R && bash tools/pmc_sq_matcher.sh ${T} > /dev/null 2>&1; cp $O/pmc_sq_matcher_${T}.txt $O/${T}_sq_counters_matcher.txt
-echo refreshed $T
+
+# the streaming kernel by waves per SIMD (variants library: LDS padding), and the C++ batch driver's rate
+cd $R && bash tools/occupancy_probe_stream.sh 8192 > $O/${T}_occupancy_stream.txt 2>&1
+cd $R && timeout -k 10 300 python3 tools/euroc_batch_rate.py > $O/${T}_euroc_batch_rate.txt 2>&1
+echo refreshed $T with occupancy scan and batch driver rate

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; F=8192
 cd /tmp; export TMPDIR=/tmp
-for S in 0 1000 40 24; do
+for S in 0 240 160 120 96 0; do
   if [ $S = 0 ]; then unset ARIA_STREAM_SEG_ROWS; else export ARIA_STREAM_SEG_ROWS=$S; fi; export ARIA_ORB_HIP_LIBRARY=$R/aria_slam_amd/libaria_orb_hip_variants.so
   rm -rf $O/seg_$S
   timeout -k 10 300 rocprofv3 --kernel-trace -d $O/seg_$S -o run -- python3 $R/tools/prof_extract.py --pairs $((F / 2)) --iters 4 --chunk $F > $O/seg_$S.log 2>&1 || { echo "$S failed"; tail -5 $O/seg_$S.log; exit 1; }
