@@ -41,13 +41,14 @@ namespace aria {
 namespace {
 
 constexpr int kRing = 16;                         // rows of the raw ring and of the score ring (power of two)
-// ARIA_STREAM_PEND_LDS (compact lists only): the record of the pending candidate batch waits for its slice in LDS instead
-// of a register (64 dwords taken from the corner list: 384 entries instead of 512, beyond which the dense scan takes over).
+// ARIA_STREAM_PEND_LDS (compact lists only): the records of the pending candidate batch wait for their slice where they are, at
+// the front of the out-list, instead of in a register: nothing is appended between the reservation (end of the NMS phase) and
+// the store (behind the next rows' take-out), so the batch is read again and dropped there.
 #ifndef ARIA_STREAM_PEND_LDS
 #define ARIA_STREAM_PEND_LDS 1
 #endif
 constexpr int kQ1 = 256;                          // survivor queue entries (appended in rounds of at most this many)
-constexpr int kQ2 = ARIA_STREAM_PEND_LDS ? 384 : 512;      // corner list entries (beyond: dense scan of the score ring)
+constexpr int kQ2 = 512;                          // corner list entries (beyond: dense scan of the score ring)
 // Compact lists (round 4): 16-bit survivor and corner entries, 4-byte candidate records, no pads -- 8192 + 2048 = 10 240 B per
 // wave: what a fourth wave per SIMD needs from the LDS side (ARIA_STREAM_WAVES4 below is the register side).
 #ifndef ARIA_STREAM_COMPACT_LDS
@@ -63,7 +64,7 @@ constexpr int kMapBytes = kRing * 256;
 constexpr int kOut = 128;                         // candidate out-list entries (record + frame), flushed 64 at a time
 #if ARIA_STREAM_COMPACT_LDS
 constexpr int kMapPad = 0;
-constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 2 * kQ1 + 2 * kQ2 + 4 * kOut + (ARIA_STREAM_PEND_LDS ? 256 : 0);      // 10 240 B per wave
+constexpr int kWaveLds = kHdrBytes + kRawBytes + kMapBytes + kMapPad + 2 * kQ1 + 2 * kQ2 + 4 * kOut;      // 10 240 B per wave
 static_assert(kWaveLds == 10240, "16 waves per CU");
 typedef uint16_t qent_t;
 #else
@@ -256,8 +257,6 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
 #if !ARIA_STREAM_COMPACT_LDS
     uint32_t* s_outf = s_out + kOut;
     static_assert(!ARIA_STREAM_PEND_LDS, "ARIA_STREAM_PEND_LDS goes with the compact lists");
-#elif ARIA_STREAM_PEND_LDS
-    uint32_t* s_pend = s_out + kOut;           // [64] records of the batch whose slice has been requested
 #endif
 
     // ---- addresses: wave-uniform 64-bit bases + 32-bit lane offsets ----
@@ -388,17 +387,22 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     bool pend_any = false;               // a batch is waiting for its slice (wave-uniform)
     // the first min(outn, 64) entries of the out-list, one per lane: record, frame, and per frame of the batch the leader
     // lane, the rank inside the frame's slice and (in the leader) the size of the slice
+#if ARIA_STREAM_COMPACT_LDS
+    // entry `lane` of the out-list as the final record: compact record = local px | row << 8 | score << 19; x and the frame come
+    // from the lane that holds the pixel
+    auto front_record = [&](bool valid, uint32_t& rec, int& frame) {
+        const uint32_t rc = valid ? s_out[lane] : 0u;
+        const uint32_t lpx = rc & 0xFFu;
+        const uint32_t li = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lpx >> 2) << 2), (int)linfo);
+        rec = ((li & 0x7FFu) + (lpx & 3u)) | (((rc >> 8) & 0x7FFu) << 11) | ((rc >> 19) << 22);
+        frame = frame0 + (int)(valid ? ((li >> 11) & 0xFFFFFu) : 0u);
+    };
+#endif
     auto take_batch = [&](uint32_t& rec, int& frame, bool& valid, uint32_t& leader, uint32_t& rank, int& my_count) {
         const int nb = min(outn, 64);
         valid = lane < nb;
 #if ARIA_STREAM_COMPACT_LDS
-        {   // compact record: local px | row << 8 | score << 19; x and the frame come from the lane that holds the pixel
-            const uint32_t rc = valid ? s_out[lane] : 0u;
-            const uint32_t lpx = rc & 0xFFu;
-            const uint32_t li = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lpx >> 2) << 2), (int)linfo);
-            rec = ((li & 0x7FFu) + (lpx & 3u)) | (((rc >> 8) & 0x7FFu) << 11) | ((rc >> 19) << 22);
-            frame = frame0 + (int)(valid ? ((li >> 11) & 0xFFFFFu) : 0u);
-        }
+        front_record(valid, rec, frame);
 #else
         rec = valid ? s_out[lane] : 0u;
         frame = frame0 + (int)(valid ? s_outf[lane] : 0u);
@@ -449,19 +453,25 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         uint32_t leader, rank;
         int frame;
         take_batch(p_rec, frame, p_valid, leader, rank, my_count);
-#if ARIA_STREAM_PEND_LDS
-        s_pend[lane] = p_rec;                // (a lane reads its own slot back: no ordering with other lanes involved)
-#endif
         if (my_count > 0) p_base = atomicAdd(A.cand_cnt + frame * kLevels, my_count);
         p_meta = (uint32_t)(frame - frame0) | (leader << 20) | (rank << 26);
         pend_any = true;
+#if !ARIA_STREAM_PEND_LDS
         drop_batch();
+#endif
     };
     auto complete_pending = [&]() {
 #if ARIA_STREAM_PEND_LDS
-        p_rec = s_pend[lane];
+        {   // the batch is still the first 64 entries of the out-list (nothing has been appended since): read it again, drop it now
+            int frame_again;
+            front_record(p_valid, p_rec, frame_again);
+            (void)frame_again;
+        }
 #endif
         store_batch(p_rec, frame0 + (int)(p_meta & 0xFFFFFu), p_valid, (p_meta >> 20) & 63u, p_meta >> 26, p_base);
+#if ARIA_STREAM_PEND_LDS
+        drop_batch();
+#endif
         p_valid = false;
         pend_any = false;
     };
