@@ -968,8 +968,8 @@ __device__ __forceinline__ void pyramid_wave(const StreamArgs& A, uint8_t* __res
 }
 
 // FOUR waves per SIMD (round 4). The kernel needs <= 128 VGPRs and <= 10 240 B of LDS per wave for that; the compact lists give
-// the LDS, and with the flat walk, the pending record in LDS and the y-table through a scalar base the allocator gets to 128
-// registers when it is told to (left alone it stops at 138: it has no reason to go below the 168 of three waves). What it
+// the LDS, and with the flat walk, the pending batch left in the out-list and the y-table through a scalar base the allocator gets to 128
+// registers when it is told to (left alone it stops at 138-140: it has no reason to go below the 168 of three waves). What it
 // still spills are five values that live through the group loop without being used in it: stored once in front of the
 // loop, loaded once behind it (24 bytes of scratch per lane, no scratch access inside the loop -- tests/test_isa_lint.py holds
 // the kernel to that). Measured A B A B on one box (tools/ab_levels.sh, 640x480 at 8192 frames): 1.481 against 1.581 us per

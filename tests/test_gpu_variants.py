@@ -66,3 +66,28 @@ def test_knn2_kernels_against_brute_force(env, variants_lib):
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad" not in out.stdout
+
+
+# Build options of the streaming kernel that the product does not take (aria_slam_amd/csrc/fast_blur_stream.hip): the
+# role-split launch (pyramid waves beside FAST/blur waves) and the unconstrained three-wave form
+# (branching walk, wide LDS lists). Each is a product-flags build with extra defines (tools/build_ab.sh), held to the golden
+# digests through the batch entry point.
+STREAM_BUILDS = {
+    "split": ["-DARIA_STREAM_SPLIT=1", "-DARIA_SCORE_SEQ=1"],
+    "three_waves": ["-DARIA_STREAM_WAVES4=0", "-DARIA_STREAM_FLAT=0", "-DARIA_STREAM_COMPACT_LDS=0", "-DARIA_STREAM_PEND_LDS=0"],
+}
+
+
+@pytest.mark.parametrize("name", sorted(STREAM_BUILDS))
+def test_stream_kernel_build_options_match_golden(name):
+    lib = os.path.join(ROOT, "build", "ab", "libopt_%s.so" % name)
+    csrc = os.path.join(ROOT, "aria_slam_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < newest:       # (a library built in the CPU container travels with the snapshot)
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_ab.sh"), "opt_" + name] + STREAM_BUILDS[name], stdout=subprocess.DEVNULL)
+    e = dict(os.environ)
+    e["ARIA_ORB_HIP_LIBRARY"] = lib
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_check.py")], env=e, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("batch (k_fast_blur_stream) OK") == 3, out.stdout
