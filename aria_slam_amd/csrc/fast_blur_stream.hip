@@ -137,6 +137,12 @@ __device__ __forceinline__ int ring_off(int y) { return ((y + 3) & (kRing - 1)) 
 #ifndef ARIA_STREAM_FLAT
 #define ARIA_STREAM_FLAT 1
 #endif
+// Pyramid step IN the walk (round 4): a source row's horizontal blend is taken from the row's dword and its two neighbours while
+// they are in registers (the walk has them for the blur), and blended with the previous row's into the output row whose lower
+// source row it is (table by source row, orb_plan.cpp) -- no second pass over the LDS ring, no y-table window, no row loop.
+#ifndef ARIA_STREAM_PYR_INWALK
+#define ARIA_STREAM_PYR_INWALK 1
+#endif
 #ifndef ARIA_STREAM_SPLIT
 #define ARIA_STREAM_SPLIT 0
 #endif
@@ -207,6 +213,7 @@ struct StreamArgs {
     const uint32_t* xt;       // tables of level l+1
     const uint32_t* yt;
     const uint32_t* xinv;
+    const uint32_t* ytr;      // pyramid step by source row of level l (always a readable table, also without a next level)
     int64_t src_fstride, blur_fstride, next_fstride;     // bytes between frames
     int cand_fstride;         // entries between frames
     int cand_cap;
@@ -317,12 +324,28 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 const uint32_t cx1 = t >> 16;
                 const int lpx = 4 * lane + (ox - 4 * R.gdw);            // local pixel of source column ox in the wave's ring row
                 xw[i] = (256u - cx1) | (cx1 << 16);
+#if ARIA_STREAM_PYR_INWALK
+                // byte index of source column ox in the register pair the pixel blends from: pixel 0 in (left neighbour, own
+                // dword), pixels 1..3 in (own dword, right neighbour) -- build_plan checks that every pair lies inside
+                (void)lpx;
+                xs[i] = 0x0C010C00u + (uint32_t)(ox - 4 * R.gdw + (i == 0 ? 4 : 0)) * 0x00010001u;
+                if (4 * host_gx + i >= gn_w) xs[i] = 0x0C0C0C0Cu;        // padding pixel of a partial last dword: zeros
+#else
                 xo[i] = (uint32_t)(lpx & ~3);
                 xs[i] = 0x0C010C00u + (uint32_t)(lpx & 3) * 0x00010001u;
+#endif
             }
             nout_off = (uint32_t)((int64_t)(R.frame - frame0) * A.next_fstride + 4 * host_gx);
         }
     }
+#if ARIA_STREAM_PYR_INWALK
+    static_assert(!ARIA_STREAM_SPLIT && ARIA_STREAM_FLAT && kG == 7, "the in-walk pyramid step belongs to the fused, flat walk");
+    // the table by source row goes through the scalar cache (wave-uniform index): seven words per group, loaded at its top
+    typedef const uint32_t __attribute__((address_space(4))) * const_u32p;
+    const const_u32p ytrs = reinterpret_cast<const_u32p>(reinterpret_cast<uint64_t>(A.ytr));
+    uint32_t hprev[4] = {0u, 0u, 0u, 0u};          // horizontal blend of the previous source row (the upper row of the next output row)
+    (void)yt; (void)xo; (void)gn_h;
+#else
     // next output row of level l+1 (wave-uniform): the first one whose upper source row lies in this segment
     int dy_next = 0;
     if (pyr && r0 > 0) {
@@ -338,6 +361,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
     uint32_t hprev[4] = {0u, 0u, 0u, 0u};
     int hprev_row = -1;
 
+#endif
     // ---- the 7-row register window in kG slots; slot = position of the row in its group (static after unrolling by kG) ----
     uint32_t RC2[kG][2], RE[kG], RW[kG];
     float RF[kG][4];
@@ -504,7 +528,13 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         }
         wave_sync();
         // y-table window of the pyramid step: refilled here, a whole walk ahead of its first use
+#if !ARIA_STREAM_PYR_INWALK
         if (pyr && dy_next + kG + 2 > yt_base + 64) { yt_base = dy_next; ytv = gload_sv<uint32_t>(reinterpret_cast<const uint8_t*>(A.yt), 4u * (uint32_t)min(yt_base + lane, gn_h - 1)); }
+#else
+        uint32_t yr[kG];
+#pragma unroll
+        for (int u = 0; u < kG; u++) yr[u] = ytrs[min(max(t0 + u, 0), h - 1)];
+#endif
         PHASE(0);
 
         if constexpr (FB) {
@@ -534,6 +564,30 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), KLO, 0u, false), false);
                 const uint32_t rs3 = __builtin_amdgcn_udot4(w2, KHI, __builtin_amdgcn_udot4(w1, KLO, 0u, false), false);
                 RF[u][0] = (float)rs0; RF[u][1] = (float)rs1; RF[u][2] = (float)rs2; RF[u][3] = (float)rs3;   // exact: < 2^16
+#if ARIA_STREAM_PYR_INWALK
+                if constexpr (PYR) {
+                    // ---- a6.1 in the walk: this row's horizontal blend for the hosted output dword (v_perm picks the two source
+                    //      bytes of a pixel out of the registers, v_dot2 weighs them: the integers of k_resize_lds), blended with
+                    //      the previous row's into the output row whose LOWER source row this is. Rows that are nobody's lower
+                    //      row (one in six), rows of another segment's output rows and lanes that host nothing store nothing. ----
+                    constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
+                    const uint32_t ye = yr[u];
+                    const uint32_t cy1 = (ye >> 16) & 0x1FFu, cyp = (256u - cy1) | (cy1 << 16);
+                    uint32_t poutw = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t pair = i == 0 ? __builtin_amdgcn_perm(w1, w0, xs[0]) : __builtin_amdgcn_perm(w2, w1, xs[i]);
+                        const uint32_t hc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, pair), __builtin_bit_cast(us2v, xw[i]), 0u, false);
+                        const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, hprev[i] | (hc << 16)),
+                                                                  __builtin_bit_cast(us2v, cyp), 32768u, false);   // < 2^24
+                        poutw = __builtin_amdgcn_perm(v, poutw, put[i]);
+                        hprev[i] = hc;
+                    }
+                    // (output rows belong to the segment that holds their UPPER source row t - 1: r0 <= t - 1 < r1)
+                    const bool out_row = (ye >> 31) != 0u && t > r0 && t <= min(r1, h - 1);
+                    if (out_row && host_gx >= 0) gstore_sv<uint32_t>(next0 + (int64_t)(ye & 0xFFFFu) * A.next_pitch, nout_off, poutw);
+                }
+#endif
 
                 const int o = t - 3;              // level row whose window [o-3, o+3] is now complete
                 // row o+d of the window lives in slot (u - 3 + d) mod kG
@@ -767,6 +821,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
         // ---- a6.1 fused: rows of level l+1 whose two source rows are in the ring now. The lane that hosts an output dword
         //      blends its 4 pixels from the ring (v_perm + v_dot2_u32_u16, the integers of k_resize_lds); the horizontal
         //      blend of the lower source row is kept for the next output row, which starts there 5 times out of 6. ----
+#if !ARIA_STREAM_PYR_INWALK
         if (pyr) {
             const int ring_last = min(t0 + kG - 1, min(t_last, h - 1));    // last level row in the ring
             constexpr uint32_t put[4] = {0x03020106u, 0x03020600u, 0x03060100u, 0x06020100u};   // byte 2 of v -> byte i
@@ -814,6 +869,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs& A, uint8_t* __rest
                 dy_next++;
             }
         }
+#endif
         PHASE(4);
     }
     if constexpr (FB) {
@@ -1054,6 +1110,14 @@ __global__ __launch_bounds__(64 * WPB) ARIA_STREAM_OCC void k_fast_blur_stream(S
     else stream_wave<WPB, false, true, false>(A, wl, lane, R, frame0, seg, stamps);
 #else
     (void)role_pyr;
+#if ARIA_STREAM_PYR_INWALK
+    // (the last level has no pyramid step: its walk is an instance of its own, without the blend)
+    if (A.next == nullptr) {
+        if (any_tail) stream_wave<WPB, true, true, false>(A, wl, lane, R, frame0, seg, stamps);
+        else stream_wave<WPB, false, true, false>(A, wl, lane, R, frame0, seg, stamps);
+        return;
+    }
+#endif
     if (any_tail) stream_wave<WPB, true, true, true>(A, wl, lane, R, frame0, seg, stamps);
     else stream_wave<WPB, false, true, true>(A, wl, lane, R, frame0, seg, stamps);
 #endif
@@ -1127,7 +1191,9 @@ void launch_fast_blur_stream(const Plan& P, const FrameSrc& S, const DeviceScrat
         if (l + 1 < kLevels) {
             const LevelGeom& gn = P.lv[l + 1];
             A.next = D.raw + gn.raw_off; A.next_fstride = P.raw_frame_bytes; A.next_pitch = gn.pitch; A.next_w = gn.w; A.next_h = gn.h;
-            A.xt = D.tab + gn.xtab; A.yt = D.tab + gn.ytab; A.xinv = D.tab + gn.xinv;
+            A.xt = D.tab + gn.xtab; A.yt = D.tab + gn.ytab; A.xinv = D.tab + gn.xinv; A.ytr = D.tab + gn.ytr;
+        } else {
+            A.ytr = D.tab + P.lv[1].ytr;          // (never used for a store: no lane hosts anything without a next level)
         }
         // (variants build: ARIA_STREAM_LDS_KB pads the workgroup's LDS to lower the occupancy -- how the kernel scales with waves per SIMD)
         static const size_t lds_pad = [] { const char* e = aria_getenv("ARIA_STREAM_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();

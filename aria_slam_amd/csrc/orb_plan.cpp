@@ -56,6 +56,7 @@ int64_t plan_tab_entries(int width, int height) {
         n += round_half_even((float)width * inv) + round_half_even((float)height * inv);
         const float inv_up = 1.0f / layer_scale(l - 1);
         n += (round_half_even((float)width * inv_up) + 3) / 4;      // xinv: one entry per dword of the level above
+        n += round_half_even((float)height * inv_up);               // ytr: one entry per row of the level above
     }
     return n + 4 * kLevels;       // (level_size_mode 1 can make a level one pixel larger)
 }
@@ -157,10 +158,42 @@ int build_plan(int width, int height, int nfeatures, int cand_cap_scale, int tie
                     if (ok) host = gs;
                 }
                 if (host < 0) P->stream_ok = 0;
-                else tab[tabpos + host] = (uint32_t)gx;
+                else {
+                    tab[tabpos + host] = (uint32_t)gx;
+                    // the walk blends from REGISTERS (own dword and both neighbours): pixel 0's two source bytes come out of
+                    // (left neighbour, own dword), pixels 1..3's out of (own dword, right neighbour) -- static operands
+                    // (pixels past the level's width -- a partial last dword -- are padding: the kernel blends zeros there)
+                    for (int i = 0; i < 4 && 4 * gx + i < g.w; i++) {
+                        const int d = (int)(xt[4 * gx + i] & 0xFFFFu) - 4 * host;
+                        if (i == 0 ? (d < -4 || d > 2) : (d < 0 || d > 6)) P->stream_ok = 0;
+                    }
+                }
             }
             tabpos += Ds;
         }
+    }
+    // (behind every other table: k_pyramid copies the span of the x / y tables into LDS, which must not grow)
+    for (int l = 1; l < kLevels; l++) {
+        LevelGeom& g = P->lv[l];
+        const LevelGeom& s = P->lv[l - 1];
+        // the pyramid step by SOURCE row: row t of the level above is the lower source row of at most one output row, whose
+        // upper source row is t - 1 (every scale near 1.2); an output row clamped to the last source row (oy = h - 1,
+        // weight 0 on the row below) takes that row with cy = 256, i.e. all weight on the row itself
+        if (tabpos + s.h > tab_capacity) return ARIA_E_INVALID;
+        g.ytr = tabpos;
+        for (int k = 0; k < s.h; k++) tab[tabpos + k] = 0u;
+        {
+            const uint32_t* yt = tab + g.ytab;
+            for (int dy = 0; dy < g.h; dy++) {
+                const int oy = (int)(yt[dy] & 0xFFFFu);
+                uint32_t cy1 = yt[dy] >> 16;
+                int rb = oy + 1;
+                if (rb > s.h - 1) { rb = s.h - 1; if (cy1 != 0) P->stream_ok = 0; cy1 = 256u; }
+                if (oy < 0 || oy > s.h - 1 || tab[tabpos + rb] != 0u) { P->stream_ok = 0; continue; }
+                tab[tabpos + rb] = (uint32_t)dy | (cy1 << 16) | 0x80000000u;
+            }
+        }
+        tabpos += s.h;
     }
     // LDS sort capacity of k_select: room for retainBest(2*quota) plus ties at the cut, power of two
     int sc = kSortCapMin;

@@ -41,6 +41,8 @@ struct LevelGeom {
     float scale;       // layerScale
     int xinv;          // offset (in uint32) of the streaming kernel's host table (level >= 1): entry g = the dword of THIS level's
                        // row that source dword g of the level above hosts in the fused pyramid step, or 0xFFFFFFFF
+    int ytr;           // offset (in uint32) of the pyramid step's table BY SOURCE ROW (level >= 1; one entry per row of the level
+                       // above): row t is the LOWER source row of output row dy -> dy | cy1 << 16 | 1 << 31, else 0
     int64_t raw_off;   // byte offset of the level inside a frame's raw-pyramid block (level 0: caller image)
     int64_t blur_off;  // byte offset inside a frame's blurred-pyramid block
 };

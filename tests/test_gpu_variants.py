@@ -69,12 +69,14 @@ def test_knn2_kernels_against_brute_force(env, variants_lib):
 
 
 # Build options of the streaming kernel that the product does not take (aria_slam_amd/csrc/fast_blur_stream.hip): the
-# role-split launch (pyramid waves beside FAST/blur waves) and the unconstrained three-wave form
-# (branching walk, wide LDS lists). Each is a product-flags build with extra defines (tools/build_ab.sh), held to the golden
+# role-split launch (pyramid waves beside FAST/blur waves), the unconstrained three-wave form
+# (branching walk, wide LDS lists) and the pyramid step as a separate phase over the LDS ring. Each is a product-flags build with extra defines (tools/build_ab.sh), held to the golden
 # digests through the batch entry point.
 STREAM_BUILDS = {
-    "split": ["-DARIA_STREAM_SPLIT=1", "-DARIA_SCORE_SEQ=1"],
-    "three_waves": ["-DARIA_STREAM_WAVES4=0", "-DARIA_STREAM_FLAT=0", "-DARIA_STREAM_COMPACT_LDS=0", "-DARIA_STREAM_PEND_LDS=0"],
+    "split": ["-DARIA_STREAM_SPLIT=1", "-DARIA_SCORE_SEQ=1", "-DARIA_STREAM_PYR_INWALK=0"],
+    "three_waves": ["-DARIA_STREAM_WAVES4=0", "-DARIA_STREAM_FLAT=0", "-DARIA_STREAM_COMPACT_LDS=0", "-DARIA_STREAM_PEND_LDS=0",
+                    "-DARIA_STREAM_PYR_INWALK=0"],
+    "pyramid_phase": ["-DARIA_STREAM_PYR_INWALK=0"],          # the pyramid step as a phase of its own over the LDS ring (until round 4)
 }
 
 
